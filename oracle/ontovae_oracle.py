@@ -1,0 +1,292 @@
+"""CPU oracle for the OntoVAE hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is a dense numpy (float32) restatement of the reference algorithm, written
+from the reference's behaviour, with every gradient worked out by hand so that it
+is independent of torch.autograd.  It exists to check the HIP path
+(onto_vae_amd) and as the `cpu_baseline` leg of bench.py.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline may import it; the product
+path never does (and fails loudly when the HIP library is missing).
+
+Parity pin: the reference ships no tests or golden vectors, so
+this oracle is pinned by fixtures generated from the *imported reference itself*
+in the build container (tools/gen_golden.py -> tests/golden/*.npz, checked by
+tests/test_oracle_golden.py).
+
+It uses the reference's dense formulation on purpose: dense 0/1 masks expanded
+with repeat_interleave, one dense Linear per depth with a prepending concat, a
+dense gradient-mask multiply, dense AdamW over every parameter and a dense clamp.
+That is what the reference costs on a CPU, so it is also the honest CPU baseline.
+
+Reference map (paths relative to /root/reference):
+  expand_masks            onto_vae/modules.py:268-275
+  encoder_forward         onto_vae/modules.py:45-50, 56-64, 74-84
+  decoder_forward         onto_vae/modules.py:303-313
+  reparameterize          onto_vae/vae_model.py:91-93 (eps supplied by the caller)
+  vae_loss                onto_vae/vae_model.py:124-129
+  train_step              onto_vae/vae_model.py:156-176 (one loop body of train_round)
+  val_step                onto_vae/vae_model.py:204-209
+  pass_data               onto_vae/vae_model.py:276-327
+  loader_batches          onto_vae/fast_data_loader.py:27-43
+  train_val_split         onto_vae/vae_model.py:233-236
+  AdamW arithmetic        torch.optim.AdamW defaults (vae_model.py:251): betas (0.9, 0.999),
+                          eps 1e-8, weight_decay 1e-2, decoupled decay, bias correction
+  BatchNorm1d arithmetic  torch.nn.BatchNorm1d defaults (modules.py:47): eps 1e-5, momentum 0.1,
+                          biased variance for normalisation, unbiased for running_var
+"""
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+ADAM_B1, ADAM_B2, ADAM_EPS, ADAM_WD = 0.9, 0.999, 1e-8, 1e-2
+
+
+def expand_masks(mask_list, nu):
+    """modules.py:271-275: inner masks repeat_interleave(nu) on both axes, last on columns only."""
+    out = []
+    for m in mask_list[:-1]:
+        m = np.asarray(m)
+        out.append(np.repeat(np.repeat(m, nu, axis=0), nu, axis=1).astype(F32))
+    out.append(np.repeat(np.asarray(mask_list[-1]), nu, axis=1).astype(F32))
+    return out
+
+
+def nu_mean(a, nu):
+    """vae_model.py:297/317: np.array(np.split(a, a.shape[1]/nu, axis=1)).mean(axis=2).T"""
+    n, c = a.shape
+    return a.reshape(n, c // nu, nu).mean(axis=2, dtype=F32).astype(F32)
+
+
+def train_val_split(n):
+    """vae_model.py:233-235."""
+    idx = np.random.RandomState(seed=42).permutation(n)
+    cut = round(len(idx) * 0.8)
+    return idx[:cut], idx[cut:]
+
+
+def loader_batches(n, batch_size, perms):
+    """fast_data_loader.py:27-43 with the per-epoch permutations supplied.
+
+    `perms` is a list with one permutation (or None for shuffle=False) per epoch.
+    The shuffle is cumulative: epoch e sees tensors[r_1][r_2]...[r_e].
+    Returns, per epoch, the list of index arrays into the ORIGINAL row order.
+    """
+    order = np.arange(n)
+    epochs = []
+    for r in perms:
+        if r is not None:
+            order = order[np.asarray(r)]
+        epochs.append([order[i:i + batch_size].copy() for i in range(0, n, batch_size)])
+    return epochs
+
+
+class OracleOntoVAE:
+    """Dense CPU OntoVAE with dropout disabled (drop = z_drop = 0), eps supplied."""
+
+    def __init__(self, mask_list, neuronnum=3):
+        self.nu = int(neuronnum)
+        self.mask_list = [np.asarray(m) for m in mask_list]
+        self.K = len(mask_list)
+        dims = [self.mask_list[0].shape[1]] + [m.shape[0] for m in self.mask_list]
+        self.layer_dims_dec = np.array(dims)                       # vae_model.py:53
+        self.latent_dim = int(dims[0] * self.nu)                   # vae_model.py:54
+        self.in_features = int(dims[-1])
+        d = np.hstack([np.array(dims[:-1]) * self.nu, dims[-1]])   # modules.py:268
+        self.layer_shapes = [(int(np.sum(d[:i + 1])), int(d[i + 1])) for i in range(len(d) - 1)]
+        self.masks = expand_masks(self.mask_list, self.nu)
+        for m, (cin, cout) in zip(self.masks, self.layer_shapes):
+            assert m.shape == (cout, cin), (m.shape, cout, cin)
+        self.p = {}          # parameters, state_dict names
+        self.buf = {}        # BN buffers
+        self.opt = None      # AdamW state
+        self.training = True
+
+    # ------------------------------------------------------------------ state
+    def param_names(self):
+        names = ["encoder.encoder.0.0.weight", "encoder.encoder.0.0.bias",
+                 "encoder.encoder.0.1.weight", "encoder.encoder.0.1.bias",
+                 "encoder.mu.0.weight", "encoder.mu.0.bias",
+                 "encoder.logvar.0.weight", "encoder.logvar.0.bias"]
+        for i in range(self.K):
+            names += [f"decoder.decoder.{i}.0.weight", f"decoder.decoder.{i}.0.bias"]
+        return names
+
+    def load_state_dict(self, sd):
+        for n in self.param_names():
+            self.p[n] = np.array(sd[n], dtype=F32, copy=True)
+        self.buf["running_mean"] = np.array(sd["encoder.encoder.0.1.running_mean"], dtype=F32, copy=True)
+        self.buf["running_var"] = np.array(sd["encoder.encoder.0.1.running_var"], dtype=F32, copy=True)
+        self.buf["num_batches_tracked"] = int(np.asarray(sd["encoder.encoder.0.1.num_batches_tracked"]))
+        L, G = self.latent_dim, self.in_features
+        assert self.p["encoder.encoder.0.0.weight"].shape == (L, G)
+        for i, (cin, cout) in enumerate(self.layer_shapes):
+            assert self.p[f"decoder.decoder.{i}.0.weight"].shape == (cout, cin)
+
+    def state_dict(self):
+        sd = {k: v.copy() for k, v in self.p.items()}
+        sd["encoder.encoder.0.1.running_mean"] = self.buf["running_mean"].copy()
+        sd["encoder.encoder.0.1.running_var"] = self.buf["running_var"].copy()
+        sd["encoder.encoder.0.1.num_batches_tracked"] = np.int64(self.buf["num_batches_tracked"])
+        return sd
+
+    # ---------------------------------------------------------------- forward
+    def encoder_forward(self, x, train):
+        p = self.p
+        h = x @ p["encoder.encoder.0.0.weight"].T + p["encoder.encoder.0.0.bias"]
+        if train:
+            B = x.shape[0]
+            if B < 2:
+                raise ValueError("Expected more than 1 value per channel when training")
+            mean = h.mean(axis=0, dtype=F32)
+            var = ((h - mean) ** 2).mean(axis=0, dtype=F32)          # biased
+            m = F32(BN_MOMENTUM)
+            self.buf["running_mean"] = (F32(1) - m) * self.buf["running_mean"] + m * mean
+            self.buf["running_var"] = (F32(1) - m) * self.buf["running_var"] + m * (var * F32(B / (B - 1)))
+            self.buf["num_batches_tracked"] += 1
+        else:
+            mean, var = self.buf["running_mean"], self.buf["running_var"]
+        invstd = (F32(1) / np.sqrt(var + F32(BN_EPS))).astype(F32)
+        xhat = (h - mean) * invstd
+        y = xhat * p["encoder.encoder.0.1.weight"] + p["encoder.encoder.0.1.bias"]
+        a = np.maximum(y, F32(0))
+        mu = a @ p["encoder.mu.0.weight"].T + p["encoder.mu.0.bias"]
+        lv = a @ p["encoder.logvar.0.weight"].T + p["encoder.logvar.0.bias"]
+        cache = dict(x=x, xhat=xhat, invstd=invstd, y=y, a=a)
+        return mu.astype(F32), lv.astype(F32), cache
+
+    def decoder_forward(self, z, collect=False):
+        out = z
+        outs, cs = [out], []
+        for i in range(self.K - 1):
+            c = out @ self.p[f"decoder.decoder.{i}.0.weight"].T + self.p[f"decoder.decoder.{i}.0.bias"]
+            cs.append(c)
+            out = np.concatenate((c, out), axis=1)                   # new block is PREPENDED
+            outs.append(out)
+        i = self.K - 1
+        recon = out @ self.p[f"decoder.decoder.{i}.0.weight"].T + self.p[f"decoder.decoder.{i}.0.bias"]
+        if collect:
+            return recon.astype(F32), outs, cs
+        return recon.astype(F32)
+
+    @staticmethod
+    def reparameterize(mu, lv, eps):
+        return (mu + eps * np.exp(F32(0.5) * lv)).astype(F32)
+
+    def forward(self, x, eps, train=None):
+        train = self.training if train is None else train
+        x = np.asarray(x, dtype=F32)
+        mu, lv, _ = self.encoder_forward(x, train)
+        z = self.reparameterize(mu, lv, np.asarray(eps, dtype=F32))
+        return self.decoder_forward(z), mu, lv
+
+    @staticmethod
+    def vae_loss(recon, mu, lv, x, kl_coeff):
+        kl = F32(-0.5) * np.sum(F32(1) + lv - mu * mu - np.exp(lv), dtype=F32)
+        rec = np.sum((recon - x) ** 2, dtype=F32)
+        return F32(rec), F32(kl), F32(rec + F32(kl_coeff) * kl)
+
+    # --------------------------------------------------------------- training
+    def _init_opt(self):
+        self.opt = {"step": 0,
+                    "m": {n: np.zeros_like(v) for n, v in self.p.items()},
+                    "v": {n: np.zeros_like(v) for n, v in self.p.items()}}
+
+    def gradients(self, x, eps, kl_coeff):
+        """Forward in train mode + hand-written backward.  Returns (rec, kl, loss, grads)."""
+        p, K = self.p, self.K
+        x = np.asarray(x, dtype=F32)
+        eps = np.asarray(eps, dtype=F32)
+        B = x.shape[0]
+        mu, lv, c = self.encoder_forward(x, True)
+        sigma = np.exp(F32(0.5) * lv)
+        z = (mu + eps * sigma).astype(F32)
+        recon, outs, _ = self.decoder_forward(z, collect=True)
+        rec, kl, loss = self.vae_loss(recon, mu, lv, x, kl_coeff)
+
+        g = {}
+        d_c = F32(2) * (recon - x)                                  # d loss / d recon
+        d_out = None
+        for i in range(K - 1, -1, -1):
+            W = p[f"decoder.decoder.{i}.0.weight"]
+            if i < K - 1:
+                n_c = W.shape[0]
+                d_c, d_rest = d_out[:, :n_c], d_out[:, n_c:]
+            g[f"decoder.decoder.{i}.0.weight"] = d_c.T @ outs[i]
+            g[f"decoder.decoder.{i}.0.bias"] = d_c.sum(axis=0, dtype=F32)
+            d_prev = d_c @ W
+            d_out = d_prev if i == K - 1 else d_rest + d_prev
+        d_z = d_out
+        kc = F32(kl_coeff)
+        d_mu = d_z + kc * mu
+        d_lv = d_z * eps * F32(0.5) * sigma + kc * F32(0.5) * (np.exp(lv) - F32(1))
+        a = c["a"]
+        g["encoder.mu.0.weight"] = d_mu.T @ a
+        g["encoder.mu.0.bias"] = d_mu.sum(axis=0, dtype=F32)
+        g["encoder.logvar.0.weight"] = d_lv.T @ a
+        g["encoder.logvar.0.bias"] = d_lv.sum(axis=0, dtype=F32)
+        d_a = d_mu @ p["encoder.mu.0.weight"] + d_lv @ p["encoder.logvar.0.weight"]
+        d_y = d_a * (c["y"] > 0)
+        xhat, invstd = c["xhat"], c["invstd"]
+        g["encoder.encoder.0.1.weight"] = (d_y * xhat).sum(axis=0, dtype=F32)
+        g["encoder.encoder.0.1.bias"] = d_y.sum(axis=0, dtype=F32)
+        d_xhat = d_y * p["encoder.encoder.0.1.weight"]
+        s1 = d_xhat.sum(axis=0, dtype=F32)
+        s2 = (d_xhat * xhat).sum(axis=0, dtype=F32)
+        d_h = (invstd / F32(B)) * (F32(B) * d_xhat - s1 - xhat * s2)
+        g["encoder.encoder.0.0.weight"] = d_h.T @ x
+        g["encoder.encoder.0.0.bias"] = d_h.sum(axis=0, dtype=F32)
+        g = {k: v.astype(F32) for k, v in g.items()}
+        return rec, kl, loss, g
+
+    def adamw(self, grads, lr):
+        """torch.optim.AdamW, single-tensor arithmetic order, fp32 state."""
+        if self.opt is None:
+            self._init_opt()
+        o = self.opt
+        o["step"] += 1
+        t = o["step"]
+        bc1 = 1.0 - ADAM_B1 ** t
+        bc2 = 1.0 - ADAM_B2 ** t
+        step_size = F32(lr / bc1)
+        bc2_sqrt = F32(math.sqrt(bc2))
+        for n in self.param_names():
+            w, gr, m, v = self.p[n], grads[n], o["m"][n], o["v"][n]
+            w *= F32(1.0 - lr * ADAM_WD)
+            m += (gr - m) * F32(1.0 - ADAM_B1)                       # lerp
+            v *= F32(ADAM_B2)
+            v += F32(1.0 - ADAM_B2) * gr * gr
+            denom = np.sqrt(v) / bc2_sqrt + F32(ADAM_EPS)
+            w -= step_size * (m / denom)
+
+    def train_step(self, x, eps, lr, kl_coeff):
+        """One body of train_round (vae_model.py:156-176).  Returns (rec, kl, loss)."""
+        rec, kl, loss, g = self.gradients(x, eps, kl_coeff)
+        for i in range(self.K):                                     # vae_model.py:168-169
+            g[f"decoder.decoder.{i}.0.weight"] *= self.masks[i]
+        self.adamw(g, lr)                                           # vae_model.py:172
+        for i in range(self.K):                                     # vae_model.py:175-176
+            n = f"decoder.decoder.{i}.0.weight"
+            self.p[n] = np.maximum(self.p[n], F32(0))
+        return rec, kl, loss
+
+    def val_step(self, x, eps, kl_coeff):
+        x = np.asarray(x, dtype=F32)
+        recon, mu, lv = self.forward(x, eps, train=False)
+        return self.vae_loss(recon, mu, lv, x, kl_coeff)
+
+    # -------------------------------------------------------------- inference
+    def pass_data(self, x, eps1, eps2, output):
+        """vae_model.py:276-327: eval mode, two eps draws, hooks on the first K-1 layers."""
+        x = np.asarray(x, dtype=F32)
+        mu, lv, _ = self.encoder_forward(x, False)
+        z1 = self.reparameterize(mu, lv, np.asarray(eps1, dtype=F32))       # get_embedding
+        z_avg = nu_mean(z1, self.nu)
+        z2 = self.reparameterize(mu, lv, np.asarray(eps2, dtype=F32))       # second forward
+        recon, _, cs = self.decoder_forward(z2, collect=True)
+        if output == "rec":
+            return recon
+        act = np.concatenate(cs, axis=1) if cs else np.zeros((x.shape[0], 0), F32)
+        return np.hstack((z_avg, nu_mean(act, self.nu))).astype(F32)

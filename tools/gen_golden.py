@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (imported from
+/root/reference) on seeded inputs.  Runs only in the build container; the reference never
+travels.  Fixtures hold data only: inputs (masks, weights, x, eps) and the reference's outputs.
+
+Usage: python tools/gen_golden.py [--out tests/golden]
+
+Determinism: weights are injected with load_state_dict from numpy seeds
+(onto_vae_amd.synthetic.random_state_dict), eps is injected by replacing
+model.reparameterize with a queue-fed version of the same formula
+(reference onto_vae/vae_model.py:91-93), dropout is disabled (drop = z_drop = 0).
+"""
+import argparse
+import io
+import os
+import sys
+from contextlib import redirect_stderr, redirect_stdout
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from onto_vae.vae_model import OntoVAE as RefOntoVAE            # noqa: E402  (the reference)
+from onto_vae.fast_data_loader import FastTensorDataLoader as RefLoader  # noqa: E402
+from onto_vae_amd.synthetic import (StubOntobj, synthetic_links, links_to_masks,  # noqa: E402
+                                    random_state_dict)
+
+
+class EpsQueue:
+    def __init__(self):
+        self.q = []
+
+    def push(self, e):
+        self.q.append(torch.tensor(e, dtype=torch.float32))
+
+    def __call__(self, mu, log_var):
+        eps = self.q.pop(0)
+        assert eps.shape == mu.shape, (eps.shape, mu.shape)
+        return mu + eps * torch.exp(0.5 * log_var)
+
+
+class RunRecorder(dict):
+    """Stands in for a Neptune run: run[key].log(value) (vae_model.py:126-128)."""
+
+    class _Series(list):
+        def log(self, v):
+            self.append(float(v))
+
+    def __missing__(self, k):
+        self[k] = RunRecorder._Series()
+        return self[k]
+
+
+def quiet(fn, *a, **k):
+    with redirect_stderr(io.StringIO()), redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def build_ref(masks, nu, sd_np, X=None):
+    onto = StubOntobj(masks, data={"d": X if X is not None else np.zeros((2, masks[-1].shape[0]))})
+    torch.manual_seed(0)
+    model = RefOntoVAE(onto, "d", neuronnum=nu, drop=0.0, z_drop=0.0)
+    sd = {k: torch.tensor(v) for k, v in sd_np.items()}
+    model.load_state_dict(sd)
+    epsq = EpsQueue()
+    model.reparameterize = epsq
+    return model, onto, epsq
+
+
+def gen_case(name, counts, G, nu, seed, B, steps, out_dir, lr=1e-3, kl_coeff=1e-4, n_inf=11, last_B=None):
+    rng = np.random.RandomState(seed)
+    off, tp, gp = synthetic_links(counts, G, rng)
+    masks = links_to_masks(off, tp, gp)
+    sd0 = random_state_dict(masks, nu, seed + 1)
+    L = counts[0] * nu
+    T = int(sum(counts))
+    Bs = [B] * steps
+    if last_B:
+        Bs[-1] = last_B
+    xs = [np.log1p(rng.poisson(0.8, size=(b, G))).astype(np.float32) for b in Bs]
+    epss = [rng.standard_normal(size=(b, L)).astype(np.float32) for b in Bs]
+
+    fx = {"nu": np.int64(nu), "K": np.int64(len(masks)), "lr": np.float64(lr), "kl_coeff": np.float64(kl_coeff),
+          "steps": np.int64(steps), "counts": np.array(counts, dtype=np.int64)}
+    for i, m in enumerate(masks):
+        fx[f"mask/{i}"] = m.astype(np.int8)
+    for k, v in sd0.items():
+        fx[f"sd0/{k}"] = v
+    for s in range(steps):
+        fx[f"x/{s}"] = xs[s]
+        fx[f"eps/{s}"] = epss[s]
+
+    # ---- forward + loss, train mode, fresh model (vae_model.py:108-129)
+    model, onto, epsq = build_ref(masks, nu, sd0)
+    model.train()
+    epsq.push(epss[0])
+    with torch.no_grad():
+        x0 = torch.tensor(xs[0])
+        recon, mu, lv = model.forward(x0)
+        run = RunRecorder()
+        loss = model.vae_loss(recon, mu, lv, x0, kl_coeff, mode="train", run=run)
+    fx["fwd/recon"], fx["fwd/mu"], fx["fwd/log_var"] = recon.numpy(), mu.numpy(), lv.numpy()
+    fx["fwd/rec_kl_loss"] = np.array([run["metrics/train/rec_loss"][0], run["metrics/train/kl_loss"][0], float(loss)],
+                                     dtype=np.float64)
+
+    # ---- `steps` bodies of train_round with AdamW defaults (vae_model.py:131-180, 251)
+    model, onto, epsq = build_ref(masks, nu, sd0)
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    run = RunRecorder()
+    losses = []
+    for s in range(steps):
+        epsq.push(epss[s])
+        losses.append(quiet(model.train_round, [(torch.tensor(xs[s]),)], lr, kl_coeff, opt, run))
+    fx["train/loss"] = np.array(losses, dtype=np.float64)
+    fx["train/rec"] = np.array(run["metrics/train/rec_loss"], dtype=np.float64)
+    fx["train/kl"] = np.array(run["metrics/train/kl_loss"], dtype=np.float64)
+    for k, v in model.state_dict().items():
+        fx[f"sdT/{k}"] = v.detach().numpy().copy()
+    names = [n for n, _ in model.named_parameters()]
+    for n, p_ in zip(names, model.parameters()):
+        st = opt.state[p_]
+        fx[f"adam_m/{n}"] = st["exp_avg"].numpy().copy()
+        fx[f"adam_v/{n}"] = st["exp_avg_sq"].numpy().copy()
+    # off-mask weights stay exactly zero
+    for i, m in enumerate(model.decoder.masks):
+        w = model.decoder.decoder[i][0].weight.detach()
+        assert float((w * (1 - m)).abs().max()) == 0.0
+
+    # ---- val step on the trained model (vae_model.py:182-213)
+    xv = np.log1p(rng.poisson(0.8, size=(n_inf, G))).astype(np.float32)
+    ev = rng.standard_normal(size=(n_inf, L)).astype(np.float32)
+    epsq.push(ev)
+    runv = RunRecorder()
+    vloss = quiet(model.val_round, [(torch.tensor(xv),)], kl_coeff, runv)
+    fx["val/x"], fx["val/eps"] = xv, ev
+    fx["val/rec_kl_loss"] = np.array([runv["metrics/val/rec_loss"][0], runv["metrics/val/kl_loss"][0], vloss])
+
+    # ---- _pass_data / perturbation on the trained model (vae_model.py:276-456)
+    Xd = np.log1p(rng.poisson(0.8, size=(n_inf, G))).astype(np.float64)
+    onto.add_dataset("inf", Xd)
+    e1 = rng.standard_normal(size=(n_inf, L)).astype(np.float32)
+    e2 = rng.standard_normal(size=(n_inf, L)).astype(np.float32)
+    fx["inf/X"], fx["inf/eps1"], fx["inf/eps2"] = Xd, e1, e2
+    epsq.push(e1); epsq.push(e2)
+    fx["inf/act"] = model.get_pathway_activities(onto, "inf")
+    epsq.push(e1); epsq.push(e2)
+    fx["inf/rec"] = model.get_reconstructed_values(onto, "inf")
+    pg = [onto.genes["1000_30"][3], onto.genes["1000_30"][G // 2]]
+    fx["inf/pert_gene_idx"] = np.array([3, G // 2], dtype=np.int64)
+    fx["inf/pert_values"] = np.array([0.0, 2.5])
+    epsq.push(e1); epsq.push(e2)
+    fx["inf/pert_act"] = model.perturbation(onto, "inf", pg, [0.0, 2.5], output="terms")
+    epsq.push(e1); epsq.push(e2)
+    fx["inf/pert_rec"] = model.perturbation(onto, "inf", pg, [0.0, 2.5], output="genes")
+    assert fx["inf/act"].shape == (n_inf, T)
+
+    path = os.path.join(out_dir, f"{name}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: K={len(masks)} G={G} L={L} T={T} steps={steps} -> {path} ({os.path.getsize(path)/1e3:.0f} kB)")
+    return fx, masks
+
+
+def gen_loader(out_dir):
+    """FastTensorDataLoader batch order under torch.manual_seed (fast_data_loader.py:31-43) and
+    the train/val split (vae_model.py:233-235)."""
+    fx = {}
+    N, B, seed, epochs = 53, 16, 1234, 3
+    X = torch.arange(N, dtype=torch.float32).reshape(N, 1) * torch.ones(1, 2)
+    torch.manual_seed(seed)
+    dl = RefLoader(X, batch_size=B, shuffle=True)
+    order = []
+    for _ in range(epochs):
+        ep = [b[0][:, 0].numpy().astype(np.int64) for b in dl]
+        assert len(ep) == len(dl)
+        order.append(np.concatenate(ep))
+    fx["N"], fx["B"], fx["seed"], fx["epochs"] = map(np.int64, (N, B, seed, epochs))
+    fx["order"] = np.stack(order)
+    dl2 = RefLoader(X, batch_size=B, shuffle=False)
+    fx["order_noshuffle"] = np.concatenate([b[0][:, 0].numpy().astype(np.int64) for b in dl2])
+    for n in (10, 1000, 1001):
+        idx = np.random.RandomState(seed=42).permutation(n)
+        fx[f"split_train/{n}"] = idx[:round(len(idx) * 0.8)]
+        fx[f"split_val/{n}"] = idx[round(len(idx) * 0.8):]
+    path = os.path.join(out_dir, "loader.npz")
+    np.savez_compressed(path, **fx)
+    print("loader ->", path)
+
+
+def check_oracle(fx, masks):
+    """Sanity at generation time: the CPU oracle against what the reference just produced."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from ontovae_oracle import OracleOntoVAE
+    nu, steps = int(fx["nu"]), int(fx["steps"])
+    sd0 = {k[4:]: v for k, v in fx.items() if k.startswith("sd0/")}
+    o = OracleOntoVAE(masks, nu)
+    o.load_state_dict(sd0)
+    worst = 0.0
+    for s in range(steps):
+        rec, kl, loss = o.train_step(fx[f"x/{s}"], fx[f"eps/{s}"], float(fx["lr"]), float(fx["kl_coeff"]))
+        worst = max(worst, abs(loss - fx["train/loss"][s]) / abs(fx["train/loss"][s]))
+    sd = o.state_dict()
+    wd = max(float(np.abs(sd[k[4:]] - v).max()) for k, v in fx.items() if k.startswith("sdT/") and v.dtype == np.float32)
+    act = o.pass_data(fx["inf/X"], fx["inf/eps1"], fx["inf/eps2"], "act")
+    print(f"   oracle vs reference: loss rel {worst:.2e}, params abs {wd:.2e}, act abs {np.abs(act - fx['inf/act']).max():.2e}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(4)
+    fx, masks = gen_case("g1_tiny", counts=[6, 9, 7], G=200, nu=3, seed=101, B=16, steps=10, out_dir=a.out, last_B=9)
+    check_oracle(fx, masks)
+    fx, masks = gen_case("g1_odd", counts=[3, 5, 4, 2], G=53, nu=2, seed=202, B=13, steps=6, out_dir=a.out, n_inf=7)
+    check_oracle(fx, masks)
+    fx, masks = gen_case("g1_nu1", counts=[5, 4], G=31, nu=1, seed=303, B=5, steps=4, out_dir=a.out, n_inf=3)
+    check_oracle(fx, masks)
+    gen_loader(a.out)
