@@ -1,0 +1,244 @@
+/*
+ * ontovae_hip.h  --  C ABI of libontovae_hip.so, the MI355X (gfx950) OntoVAE hot path.
+ *
+ * The reference (hdsu-bioquant/onto-vae) is pure Python on top of torch; it has no FFI.  Its
+ * "plugin API" for this path is the Python class surface of onto_vae/vae_model.py:OntoVAE.  Each
+ * entry point below therefore names the reference function (file:line, relative to the reference
+ * root) whose arithmetic it replaces; the Python host layer (onto_vae_amd/) mirrors the reference
+ * classes one to one and is the only caller that ships.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every device pointer is fp32/int32 HBM owned by the caller
+ *    (torch allocates it; this library allocates no device memory);
+ *  - every device entry point is asynchronous on `stream` (a hipStream_t passed as void*) and
+ *    never synchronises; scalars (losses) are written to device memory;
+ *  - return value 0 = ok, negative = error; ontovae_last_error() gives the message;
+ *  - activations inside the library are FEATURE-MAJOR: a [F, ldb] fp32 matrix, one row per
+ *    feature, batch along the contiguous axis (ldb = B rounded up to 64).  Caller-facing
+ *    tensors (x, eps, mu, log_var, recon, activities) stay sample-major like the reference's.
+ */
+#ifndef ONTOVAE_HIP_H
+#define ONTOVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ONTOVAE_OK 0
+#define ONTOVAE_EINVAL (-1)
+#define ONTOVAE_EHIP (-2)
+#define ONTOVAE_ENOMEM (-3)
+
+const char* ontovae_last_error(void);
+/* ABI version of this header; the host layer refuses a library that reports another one. */
+int ontovae_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Mask packing (host side, no GPU needed).
+ *
+ * Replaces the dense mask expansion of OntoDecoder.__init__ (onto_vae/modules.py:268-275:
+ * repeat_interleave(neuronnum) on both axes of the inner masks, on the columns of the last) and
+ * the dense gradient-mask multiply of train_round (onto_vae/vae_model.py:168-169).  Input is
+ * the reference's own mask list format, Ontobj.masks[key]['decoder'] (onto_vae/ontobj.py:386-392):
+ * mask i has rows = level i+1, columns = [level i | ... | level 0]; the last mask is [G, T].
+ *
+ * Node space.  The decoder is ONE sparse lower-triangular operator over C + G nodes:
+ *   nodes [0, C)      the activation panel, C = nu * T, laid out as the reference's final
+ *                     concatenation out_{K-1} = [level K-1 | ... | level 1 | level 0 (z)]
+ *                     (onto_vae/modules.py:308-310), nu adjacent features per term;
+ *   nodes [C, C+G)    the genes (reconstruction).
+ * Packed forms, both over expanded (per-neuron) entries, sorted, no duplicates:
+ *   CSR  rowptr[C+G+1], colidx[nnz]            entry k of row n:  W[n, colidx[k]] = vals[k]
+ *   CSC  cscptr[C+1], csc_row[nnz], csc_k[nnz] entry of column p: W[csc_row, p] = vals[csc_k]
+ * level_off[K+1] gives the node range of each forward level: level d (1..K-1) is nodes
+ * [level_off[d], level_off[d-1]) ... see ontovae_plan_levels().
+ * -------------------------------------------------------------------------------------------*/
+typedef struct ontovae_plan ontovae_plan_t;
+
+typedef struct ontovae_dims {
+    int32_t G;        /* genes = in_features                        (vae_model.py:50) */
+    int32_t T;        /* terms                                                         */
+    int32_t K;        /* decoder layers = number of masks                              */
+    int32_t nu;       /* neuronnum                                   (vae_model.py:56) */
+    int32_t L;        /* latent width = nu * n_0                     (vae_model.py:54) */
+    int32_t C;        /* panel width  = nu * T                                         */
+    int64_t nnz;      /* structurally non-zero decoder weights (expanded)              */
+    int64_t nnz_links;/* ones in the input masks                                       */
+} ontovae_dims_t;
+
+/* masks[i]: row-major uint8 [rows[i], cols[i]], values 0/1.  Shapes are validated against the
+ * reference's layout rule (cols[i] = sum of the level sizes so far). */
+int ontovae_plan_create(int32_t K, const uint8_t* const* masks, const int32_t* rows,
+                        const int32_t* cols, int32_t nu, ontovae_plan_t** out);
+/* Same plan from a link list (child, parent) in mask coordinates: layer[i], row[i], col[i] name a
+ * one in mask layer[i].  This is the dense-free path for large ontologies. */
+int ontovae_plan_create_from_links(int32_t K, const int32_t* rows, const int32_t* cols, int32_t nu,
+                                   int64_t n_links, const int32_t* layer, const int32_t* row,
+                                   const int32_t* col, ontovae_plan_t** out);
+void ontovae_plan_destroy(ontovae_plan_t* plan);
+int ontovae_plan_dims(const ontovae_plan_t* plan, ontovae_dims_t* out);
+/* level_node_begin/end[d], d = 0..K: node range of level d (0 = z, K = genes). */
+int ontovae_plan_levels(const ontovae_plan_t* plan, int32_t* node_begin, int32_t* node_end);
+/* Copy the packed arrays out (host buffers sized from ontovae_plan_dims). */
+int ontovae_plan_export(const ontovae_plan_t* plan, int32_t* rowptr, int32_t* colidx,
+                        int32_t* cscptr, int32_t* csc_row, int32_t* csc_k);
+/* Dense coordinates of every packed entry, in vals order: entry k is
+ * decoder.decoder[layer[k]][0].weight[row[k], col[k]] of the reference's state_dict. */
+int ontovae_plan_entry_coords(const ontovae_plan_t* plan, int32_t* layer, int32_t* row, int32_t* col);
+/* Node id of bias element j of layer i: used to map decoder.decoder[i][0].bias <-> dec_bias. */
+int ontovae_plan_layer_node0(const ontovae_plan_t* plan, int32_t layer, int32_t* node0, int32_t* n_out);
+/* Unpack layer i back into the reference's EXPANDED dense mask (uint8 [out_i, in_i]); the
+ * bit-exactness check is unpack(pack(M)) == OntoDecoder.masks[i]. */
+int ontovae_plan_unpack_mask(const ontovae_plan_t* plan, int32_t layer, uint8_t* out, int64_t out_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Device context: dimensions + device pointers, filled by the caller.
+ * Parameters live in ONE flat fp32 buffer `P` (so that a data-parallel gradient exchange is a
+ * few large buffers); `M`, `V` (AdamW moments) and `Gr` (gradients, only used when
+ * grads_to_buffer != 0) have the same layout.  Offsets in floats:
+ * -------------------------------------------------------------------------------------------*/
+typedef struct ontovae_layout {
+    int64_t W0;      /* [L, G]   encoder.encoder.0.0.weight                                   */
+    int64_t b0;      /* [L]      encoder.encoder.0.0.bias                                     */
+    int64_t gamma;   /* [L]      encoder.encoder.0.1.weight                                   */
+    int64_t beta;    /* [L]      encoder.encoder.0.1.bias                                     */
+    int64_t Wh;      /* [2L, L]  rows 0..L-1 encoder.mu.0.weight, rows L..2L-1 encoder.logvar  */
+    int64_t bh;      /* [2L]                                                                  */
+    int64_t dec_vals;/* [nnz]    packed decoder weights, CSR order                            */
+    int64_t dec_bias;/* [C+G]    decoder biases by node id (entries of the z level unused)    */
+    int64_t total;   /* floats in P                                                           */
+} ontovae_layout_t;
+
+int ontovae_param_layout(const ontovae_dims_t* dims, ontovae_layout_t* out);
+
+typedef struct ontovae_ctx {
+    ontovae_dims_t dims;
+    ontovae_layout_t lay;
+    /* parameters and optimizer state (device) */
+    float* P;
+    float* M;
+    float* V;
+    float* Gr;                 /* may be NULL unless grads_to_buffer */
+    float* bn_rmean;           /* [L] running_mean  */
+    float* bn_rvar;            /* [L] running_var   */
+    int64_t* bn_nbt;           /* [1] num_batches_tracked */
+    /* packed decoder (device) */
+    const int32_t* rowptr;
+    const int32_t* colidx;
+    const int32_t* cscptr;
+    const int32_t* csc_row;
+    const int32_t* csc_k;
+    /* level schedule (host arrays, K+1 entries each) */
+    const int32_t* level_begin;
+    const int32_t* level_end;
+    /* workspace (device), ontovae_workspace_bytes(dims, max_batch) bytes, 256-B aligned */
+    void* workspace;
+    int64_t workspace_bytes;
+    int32_t max_batch;
+    /* dropout (train mode only) and eps generation */
+    float drop;                /* Encoder dropout p            (modules.py:48) */
+    float z_drop;              /* latent dropout p             (modules.py:58, 63) */
+    uint64_t seed;             /* Philox key for dropout masks and internally drawn eps */
+} ontovae_ctx_t;
+
+int64_t ontovae_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch);
+
+/* AdamW hyper-parameters of one step, pre-folded on the host in double like torch does
+ * (torch.optim.AdamW defaults at onto_vae/vae_model.py:251). */
+typedef struct ontovae_adamw {
+    float decay_mul;     /* 1 - lr * weight_decay          */
+    float one_m_beta1;   /* 1 - beta1                      */
+    float beta2;
+    float one_m_beta2;   /* 1 - beta2                      */
+    float step_size;     /* lr / (1 - beta1^t)             */
+    float bc2_sqrt;      /* sqrt(1 - beta2^t)              */
+    float eps;
+} ontovae_adamw_t;
+
+/* Batch addressing.  The batcher keeps the whole dataset X [N, G] fp32 resident in HBM and hands
+ * out batches as (X, row index list): row b of the batch is X[xidx[b], :].  xidx == NULL means
+ * rows 0..B-1 of `x` (a plain [B, G] batch like the reference's data[0].to(device),
+ * onto_vae/fast_data_loader.py:41, onto_vae/vae_model.py:156). */
+
+/* OntoVAE.forward (onto_vae/vae_model.py:108-118) = Encoder.forward (modules.py:74-84) +
+ * reparameterize (vae_model.py:91-93) + OntoDecoder.forward (modules.py:303-313).
+ * eps: [B, L] sample-major or NULL (drawn internally from seed/rng_offset).
+ * Outputs (any may be NULL): recon [B, G], mu [B, L], log_var [B, L], sample-major.
+ * train != 0: BN uses batch statistics and updates the running buffers, dropout is on. */
+int ontovae_forward(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B,
+                    const float* eps, uint64_t rng_offset, int32_t train, float* recon, float* mu,
+                    float* log_var, void* stream);
+
+/* One body of OntoVAE.train_round (onto_vae/vae_model.py:156-176): forward, vae_loss
+ * (vae_model.py:124-129), backward, gradient mask (:168-169, implicit: gradients exist only at
+ * mask positions), AdamW (:172) and the clamp of decoder weights at 0 (:175-176).
+ * loss_out: device float[3] = {rec_loss, kl_loss, rec + kl_coeff * kl}.
+ * apply_update != 0: fused AdamW in the weight-gradient kernels (single GPU).
+ * apply_update == 0: gradients are written to ctx->Gr (same layout as P) and nothing is updated;
+ *   BN batch statistics are local to this rank (see ontovae_train_step_dp for SyncBN).
+ *   The caller all-reduces Gr and calls ontovae_adamw_apply. */
+int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B,
+                       const float* eps, uint64_t rng_offset, float kl_coeff,
+                       const ontovae_adamw_t* opt, int32_t apply_update, float* loss_out,
+                       void* stream);
+
+/* Data-parallel step in three phases around the caller's collectives (RCCL via torch.distributed);
+ * the reference has no counterpart (single device), the contract is "equal to the single-device
+ * step on the global batch" (SURVEY.md 8(e)):
+ *   phase 0: encoder GEMM + local BN partial statistics -> bn_stats [2, L] {sum, sum of squares}
+ *            caller: all-reduce SUM of bn_stats, passes global batch size in B_global
+ *   phase 1: BN normalise .. decoder .. backward down to BN -> bn_bwd_stats [2, L] {sum dy, sum dy*xhat}
+ *            caller: all-reduce SUM of bn_bwd_stats
+ *   phase 2: BN backward, dW0; all gradients land in ctx->Gr; loss_out holds LOCAL rec/kl sums.
+ *            caller: all-reduce SUM of Gr (+ loss_out), then ontovae_adamw_apply. */
+int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, const float* x, const int32_t* xidx,
+                          int32_t B, int32_t B_global, const float* eps, uint64_t rng_offset,
+                          float kl_coeff, float* bn_stats, float* bn_bwd_stats, float* loss_out,
+                          void* stream);
+
+/* torch.optim.AdamW.step over the flat buffers (vae_model.py:172) + clamp(0) of the packed
+ * decoder weights (vae_model.py:175-176), reading gradients from ctx->Gr. */
+int ontovae_adamw_apply(const ontovae_ctx_t* ctx, const ontovae_adamw_t* opt, void* stream);
+
+/* One body of OntoVAE.val_round (onto_vae/vae_model.py:204-209): eval-mode forward + vae_loss. */
+int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B,
+                      const float* eps, uint64_t rng_offset, float kl_coeff, float* loss_out,
+                      void* stream);
+
+/* OntoVAE._pass_data (onto_vae/vae_model.py:276-327), eval mode.  eps1 feeds get_embedding
+ * (:294), eps2 the second forward (:314); NULL = drawn internally.
+ * act_out: [B, T] sample-major nu-averaged activities hstack((z, act)) (:297, :317, :325), or NULL
+ * rec_out: [B, G] sample-major reconstruction (:327), or NULL (then the gene layer is skipped). */
+int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B,
+                      const float* eps1, const float* eps2, uint64_t rng_offset, float* act_out,
+                      int64_t act_ld, float* rec_out, int64_t rec_ld, void* stream);
+
+/* OntoDecoder.forward alone (onto_vae/modules.py:303-313) on a caller-supplied z [B, L]:
+ * the "decoder-only sparse throughput" leg of the inference benchmark. */
+int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z, int32_t B, float* act_out,
+                            int64_t act_ld, float* rec_out, int64_t rec_ld, void* stream);
+
+/* HBM-resident batcher helpers (replace onto_vae/fast_data_loader.py:33-34 on the device):
+ * order_out[i] = order_in[perm[i]]  (the reference's cumulative in-place shuffle t[r]);
+ * gather: out[b, :] = X[idx[b], :]. */
+int ontovae_compose_order(const int32_t* order_in, const int64_t* perm, int32_t* order_out, int64_t n,
+                          void* stream);
+int ontovae_gather_rows(const float* X, int64_t ld, const int32_t* idx, int32_t B, int32_t G, float* out,
+                        void* stream);
+
+/* Dense <-> packed decoder weights on the device (state_dict import/export):
+ * scatter: dense[layer row/col of entry k] = vals[k] for the entries of `layer` (dense pre-zeroed);
+ * gather:  vals[k] = dense[...]. entry_row/entry_col are the device copies of
+ * ontovae_plan_entry_coords restricted to [k0, k1). */
+int ontovae_vals_to_dense(const float* vals, const int32_t* entry_row, const int32_t* entry_col,
+                          int64_t k0, int64_t k1, float* dense, int64_t ld, void* stream);
+int ontovae_dense_to_vals(const float* dense, int64_t ld, const int32_t* entry_row,
+                          const int32_t* entry_col, int64_t k0, int64_t k1, float* vals, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONTOVAE_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libontovae_hip.so (the C ABI declared in include/ontovae_hip.h).
+
+The library is built in-tree by onto_vae_amd/build.py (hipcc, gfx950).  There is no fallback:
+if it is missing, loading raises, and every compute entry point of the package fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libontovae_hip.so")
+ABI_VERSION = 1
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f32p = C.POINTER(C.c_float)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class Dims(C.Structure):
+    _fields_ = [("G", C.c_int32), ("T", C.c_int32), ("K", C.c_int32), ("nu", C.c_int32), ("L", C.c_int32),
+                ("C", C.c_int32), ("nnz", C.c_int64), ("nnz_links", C.c_int64)]
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("W0", "b0", "gamma", "beta", "Wh", "bh", "dec_vals", "dec_bias", "total")]
+
+
+class Ctx(C.Structure):
+    _fields_ = [("dims", Dims), ("lay", Layout),
+                ("P", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p), ("Gr", C.c_void_p),
+                ("bn_rmean", C.c_void_p), ("bn_rvar", C.c_void_p), ("bn_nbt", C.c_void_p),
+                ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("cscptr", C.c_void_p), ("csc_row", C.c_void_p),
+                ("csc_k", C.c_void_p),
+                ("level_begin", c_i32p), ("level_end", c_i32p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_batch", C.c_int32),
+                ("drop", C.c_float), ("z_drop", C.c_float), ("seed", C.c_uint64)]
+
+
+class AdamW(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("decay_mul", "one_m_beta1", "beta2", "one_m_beta2", "step_size", "bc2_sqrt", "eps")]
+
+
+class OntoVAEHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OntoVAEHipError(
+            f"{LIB_PATH} not found: build it with `python -m onto_vae_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the OntoVAE hot path.")
+    L = C.CDLL(LIB_PATH)
+    L.ontovae_last_error.restype = C.c_char_p
+    L.ontovae_abi_version.restype = C.c_int
+    if L.ontovae_abi_version() != ABI_VERSION:
+        raise OntoVAEHipError(f"libontovae_hip.so reports ABI {L.ontovae_abi_version()}, expected {ABI_VERSION}: rebuild")
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+    sig = {
+        "ontovae_plan_create": [i32, C.POINTER(c_u8p), c_i32p, c_i32p, i32, C.POINTER(vp)],
+        "ontovae_plan_create_from_links": [i32, c_i32p, c_i32p, i32, i64, c_i32p, c_i32p, c_i32p, C.POINTER(vp)],
+        "ontovae_plan_dims": [vp, C.POINTER(Dims)],
+        "ontovae_plan_levels": [vp, c_i32p, c_i32p],
+        "ontovae_plan_export": [vp, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
+        "ontovae_plan_entry_coords": [vp, c_i32p, c_i32p, c_i32p],
+        "ontovae_plan_layer_node0": [vp, i32, c_i32p, c_i32p],
+        "ontovae_plan_unpack_mask": [vp, i32, c_u8p, i64],
+        "ontovae_param_layout": [C.POINTER(Dims), C.POINTER(Layout)],
+        "ontovae_forward": [C.POINTER(Ctx), vp, vp, i32, vp, u64, i32, vp, vp, vp, vp],
+        "ontovae_train_step": [C.POINTER(Ctx), vp, vp, i32, vp, u64, f32, C.POINTER(AdamW), i32, vp, vp],
+        "ontovae_train_step_dp": [C.POINTER(Ctx), i32, vp, vp, i32, i32, vp, u64, f32, vp, vp, vp, vp],
+        "ontovae_adamw_apply": [C.POINTER(Ctx), C.POINTER(AdamW), vp],
+        "ontovae_eval_step": [C.POINTER(Ctx), vp, vp, i32, vp, u64, f32, vp, vp],
+        "ontovae_pass_data": [C.POINTER(Ctx), vp, vp, i32, vp, vp, u64, vp, i64, vp, i64, vp],
+        "ontovae_decoder_forward": [C.POINTER(Ctx), vp, i32, vp, i64, vp, i64, vp],
+        "ontovae_compose_order": [vp, vp, vp, i64, vp],
+        "ontovae_gather_rows": [vp, i64, vp, i32, i32, vp, vp],
+        "ontovae_vals_to_dense": [vp, vp, vp, i64, i64, vp, i64, vp],
+        "ontovae_dense_to_vals": [vp, i64, vp, vp, i64, i64, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.ontovae_plan_destroy.argtypes = [vp]
+    L.ontovae_plan_destroy.restype = None
+    L.ontovae_workspace_bytes.argtypes = [C.POINTER(Dims), i32]
+    L.ontovae_workspace_bytes.restype = C.c_int64
+    _lib = L
+    return L
+
+
+EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", "ontovae_plan_create_from_links",
+            "ontovae_plan_destroy", "ontovae_plan_dims", "ontovae_plan_levels", "ontovae_plan_export",
+            "ontovae_plan_entry_coords", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
+            "ontovae_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
+            "ontovae_adamw_apply", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
+            "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals"]
+
+
+def check(rc, what=""):
+    """Turn a negative return code into a Python exception carrying the library's message."""
+    if rc == 0:
+        return
+    msg = lib().ontovae_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}")
+    raise OntoVAEHipError(f"{what}: {msg} (rc={rc})")

@@ -1,0 +1,1152 @@
+// HIP kernels + C ABI entry points of the OntoVAE hot path (gfx950 / MI355X only).
+//
+// Layout rule: inside the library every activation is FEATURE-MAJOR, [features, ldb] fp32 with
+// the batch contiguous (ldb = B rounded up to 64).  The ontology decoder is then a gather-SpMM
+// whose every access is a coalesced row read: Y[n, :] = sum_k W[n, c_k] * ACT[c_k, :].
+// The dense encoder runs on fp32 MFMA (ontovae_gemm.h).
+#include "ontovae_internal.h"
+#include "ontovae_device.h"
+#include "ontovae_gemm.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#define OV_HIP_CHECK(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            ontovae_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ONTOVAE_EHIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+#define OV_LAUNCH_CHECK() OV_HIP_CHECK(hipGetLastError())
+
+// batch columns per wave pass (64 lanes x VEC) and the padded row length, a multiple of it
+static inline int ov_vec(int B) { return B <= 64 ? 1 : (B <= 128 ? 2 : 4); }
+static inline int ov_ldb(int B) { const int q = 64 * ov_vec(B); return (B + q - 1) / q * q; }
+
+// =================================================================================================
+// Workspace
+// =================================================================================================
+struct OvWs {
+    float *slab, *xhat, *a, *mulv, *epsw, *act, *d, *dmulv, *da, *dh;
+    float *bn_mean, *bn_invstd, *bn_bwd_local;
+    float *rec_part, *kl_part;
+    int64_t slab_floats;
+    int npart_max;
+};
+
+// split-K factor of the encoder forward GEMM (M = L, N = B, K = G): enough slabs to fill the chip
+static int ov_enc_splitk(int L, int B, int G) {
+    const int tiles = ((L + 63) / 64) * ((B + 63) / 64);
+    int s = (768 + tiles - 1) / tiles;
+    const int smax = std::max(1, G / 256);
+    s = std::max(1, std::min(std::min(s, 64), smax));
+    return s;
+}
+
+static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs* ws) {
+    const int64_t ldb = ov_ldb(max_batch);
+    const int64_t L = d.L, C = d.C, G = d.G;
+    int64_t slab = 0;
+    for (int b = 64; b <= ldb; b += 64)
+        slab = std::max<int64_t>(slab, (int64_t)ov_enc_splitk(d.L, b, d.G) * L * ov_ldb(b));
+    const int64_t npart = ((G + 3) / 4) * (ldb / 64) + 1024;
+    int64_t off = 0;
+    auto take = [&](int64_t n) {
+        float* p = base ? reinterpret_cast<float*>(base) + off : nullptr;
+        off += (n + 63) / 64 * 64;
+        return p;
+    };
+    OvWs w;
+    w.slab = take(slab);
+    w.xhat = take(L * ldb);
+    w.a = take(L * ldb);
+    w.mulv = take(2 * L * ldb);
+    w.epsw = take(L * ldb);
+    w.act = take(C * ldb);
+    w.d = take((C + G) * ldb);
+    w.dmulv = take(2 * L * ldb);
+    w.da = take(L * ldb);
+    w.dh = take(L * ldb);
+    w.bn_mean = take(L);
+    w.bn_invstd = take(L);
+    w.bn_bwd_local = take(2 * L);
+    w.rec_part = take(npart);
+    w.kl_part = take(npart);
+    w.slab_floats = slab;
+    w.npart_max = (int)npart;
+    if (ws) *ws = w;
+    return off * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t ontovae_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch) {
+    if (!dims || max_batch < 1) return -1;
+    return ov_carve(*dims, max_batch, nullptr, nullptr);
+}
+
+// =================================================================================================
+// Encoder: BatchNorm (+ dropout + ReLU), feature-major, one wave per feature
+// =================================================================================================
+// h[l, b] = b0[l] + sum_s slab[s][l][b]                 (split-K combine of x W0^T, modules.py:46)
+// train: batch statistics (biased variance), running buffers updated (modules.py:47)
+// a = relu(dropout(gamma * xhat + beta))                (modules.py:47-49: BN, Dropout, ReLU)
+// mode: 0 eval (running stats), 1 train fused, 2 DP phase 0 (h + local mean/M2 only),
+//       3 DP phase 1 (normalise with the supplied global mean/var; h already in xhat)
+__global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict__ slab, int S, int64_t slab_stride,
+                                                       const float* __restrict__ b0, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ rmean,
+                                                       float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                                       float* __restrict__ xhat, float* __restrict__ a,
+                                                       float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                       float* __restrict__ stats, int L, int B, int Bglobal, int ldb,
+                                                       int mode, float drop, uint64_t seed, uint64_t rng_off) {
+    const int l = blockIdx.x * 4 + ov_wave_id();
+    if (l >= L) return;
+    const int lane = ov_lane();
+    float* xr = xhat + (int64_t)l * ldb;
+    float* ar = a + (int64_t)l * ldb;
+    float mean, var;
+    if (mode != 3) {
+        const float bias = b0[l];
+        float s = 0.f;
+        for (int b = lane; b < ldb; b += 64) {
+            float h = 0.f;
+            if (b < B) {
+                for (int z = 0; z < S; ++z) h += slab[(int64_t)z * slab_stride + (int64_t)l * ldb + b];
+                h += bias;
+                s += h;
+            }
+            xr[b] = h;
+        }
+        if (mode == 0) {
+            mean = rmean[l];
+            var = rvar[l];
+        } else {
+            mean = ov_wave_sum(s) / (float)B;
+            float q = 0.f;
+            for (int b = lane; b < B; b += 64) {
+                const float dlt = xr[b] - mean;
+                q += dlt * dlt;
+            }
+            q = ov_wave_sum(q);
+            if (mode == 2) {
+                if (lane == 0) {
+                    stats[l] = mean;
+                    stats[L + l] = q;
+                }
+                return;
+            }
+            var = q / (float)B;
+        }
+    } else {
+        mean = stats[l];
+        var = stats[L + l];
+    }
+    if (mode == 1 || mode == 3) {
+        if (lane == 0) {
+            const float mom = 0.1f;
+            const float nb = (float)Bglobal;
+            rmean[l] = (1.f - mom) * rmean[l] + mom * mean;
+            rvar[l] = (1.f - mom) * rvar[l] + mom * (var * (nb / (nb - 1.f)));
+            if (l == 0) *nbt += 1;
+        }
+    }
+    const float invstd = 1.0f / sqrtf(var + 1e-5f);
+    if (lane == 0) {
+        mean_out[l] = mean;
+        invstd_out[l] = invstd;
+    }
+    const float g = gamma[l], be = beta[l];
+    const bool dropping = (mode != 0) && drop > 0.f;
+    for (int b = lane; b < ldb; b += 64) {
+        float xh = 0.f, y = 0.f;
+        if (b < B) {
+            xh = (xr[b] - mean) * invstd;
+            y = xh * g + be;
+            if (dropping) y *= ov_dropout_scale(drop, seed, rng_off, OV_RNG_DROP, (uint64_t)l * 0x100000000ull + b);
+            y = fmaxf(y, 0.f);
+        }
+        xr[b] = xh;
+        ar[b] = y;
+    }
+}
+
+// BN backward (+ ReLU, dropout), one wave per feature.  da = dL/da.
+//   dy = da * [a > 0] * keep;  dgamma = sum dy*xhat;  dbeta = sum dy
+//   dh = gamma * invstd / Bg * (Bg * dy - dbeta - xhat * dgamma)
+// mode 1: fused single GPU (local sums are global), then AdamW on gamma, beta, b0 or grads to Gr
+// mode 2: DP phase 1 tail: write dy into dh buffer and local sums to bwd_local/bwd_stats
+// mode 3: DP phase 2 head: read dy from dh, global sums from bwd_stats; grads (LOCAL sums) to Gr
+__global__ __launch_bounds__(256) void ov_bn_bwd_kernel(const float* __restrict__ da, const float* __restrict__ a,
+                                                       const float* __restrict__ xhat, const float* __restrict__ invstd,
+                                                       float* __restrict__ P_gamma, float* __restrict__ P_beta,
+                                                       float* __restrict__ P_b0, float* __restrict__ M_gamma,
+                                                       float* __restrict__ M_beta, float* __restrict__ M_b0,
+                                                       float* __restrict__ V_gamma, float* __restrict__ V_beta,
+                                                       float* __restrict__ V_b0, float* __restrict__ G_gamma,
+                                                       float* __restrict__ G_beta, float* __restrict__ G_b0,
+                                                       float* __restrict__ dh, float* __restrict__ bwd_local,
+                                                       float* __restrict__ bwd_stats, int L, int B, int Bglobal, int ldb,
+                                                       int mode, int apply_update, OvAdam adam, float drop, uint64_t seed,
+                                                       uint64_t rng_off) {
+    const int l = blockIdx.x * 4 + ov_wave_id();
+    if (l >= L) return;
+    const int lane = ov_lane();
+    const int64_t ro = (int64_t)l * ldb;
+    float sdy = 0.f, sdyx = 0.f;
+    if (mode != 3) {
+        for (int b = lane; b < ldb; b += 64) {
+            float dy = 0.f;
+            if (b < B) {
+                dy = a[ro + b] > 0.f ? da[ro + b] : 0.f;
+                if (drop > 0.f) dy *= ov_dropout_scale(drop, seed, rng_off, OV_RNG_DROP, (uint64_t)l * 0x100000000ull + b);
+                sdy += dy;
+                sdyx += dy * xhat[ro + b];
+            }
+            dh[ro + b] = dy;
+        }
+        sdy = ov_wave_sum(sdy);
+        sdyx = ov_wave_sum(sdyx);
+        if (mode == 2) {
+            if (lane == 0) {
+                bwd_local[l] = sdy; bwd_local[L + l] = sdyx;
+                bwd_stats[l] = sdy; bwd_stats[L + l] = sdyx;
+            }
+            return;
+        }
+    }
+    float gdy = sdy, gdyx = sdyx;          // global sums
+    if (mode == 3) {
+        gdy = bwd_stats[l]; gdyx = bwd_stats[L + l];
+        sdy = bwd_local[l]; sdyx = bwd_local[L + l];
+    }
+    const float g = P_gamma[l];
+    const float is = invstd[l];
+    const float nb = (float)Bglobal;
+    const float scale = g * is / nb;
+    float sdh = 0.f;
+    for (int b = lane; b < ldb; b += 64) {
+        float v = 0.f;
+        if (b < B) {
+            v = scale * (nb * dh[ro + b] - gdy - xhat[ro + b] * gdyx);
+            sdh += v;
+        }
+        dh[ro + b] = v;
+    }
+    sdh = ov_wave_sum(sdh);
+    if (lane == 0) {
+        if (apply_update) {
+            float w, m, v;
+            w = P_gamma[l]; m = M_gamma[l]; v = V_gamma[l]; ov_adamw(w, m, v, sdyx, adam, false); P_gamma[l] = w; M_gamma[l] = m; V_gamma[l] = v;
+            w = P_beta[l];  m = M_beta[l];  v = V_beta[l];  ov_adamw(w, m, v, sdy, adam, false);  P_beta[l] = w;  M_beta[l] = m;  V_beta[l] = v;
+            w = P_b0[l];    m = M_b0[l];    v = V_b0[l];    ov_adamw(w, m, v, sdh, adam, false);  P_b0[l] = w;    M_b0[l] = m;    V_b0[l] = v;
+        } else {
+            G_gamma[l] = sdyx; G_beta[l] = sdy; G_b0[l] = sdh;
+        }
+    }
+}
+
+// =================================================================================================
+// Latent: z_drop dropout on the heads, reparameterisation, KL
+// =================================================================================================
+// mulv[0:L] = mu, mulv[L:2L] = log_var (feature-major, bias already added by the GEMM epilogue).
+// z = mu + eps * exp(0.5 * log_var)     (vae_model.py:91-93)  -> panel rows of level 0
+// kl = -0.5 * sum(1 + lv - mu^2 - exp(lv))   (vae_model.py:124), block partials in kl_part
+__global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mulv, const float* __restrict__ eps,
+                                                        float* __restrict__ epsw, float* __restrict__ zrows,
+                                                        float* __restrict__ kl_part, int L, int B, int ldb, int train,
+                                                        float z_drop, uint64_t seed, uint64_t rng_off, uint32_t eps_stream,
+                                                        int write_kl) {
+    const int64_t n = (int64_t)L * ldb;
+    float kl = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int l = (int)(idx / ldb), b = (int)(idx % ldb);
+        float z = 0.f, e = 0.f;
+        if (b < B) {
+            float mu = mulv[idx], lv = mulv[n + idx];
+            if (train && z_drop > 0.f) {
+                mu *= ov_dropout_scale(z_drop, seed, rng_off, OV_RNG_ZDROP_MU, (uint64_t)l * 0x100000000ull + b);
+                lv *= ov_dropout_scale(z_drop, seed, rng_off, OV_RNG_ZDROP_LV, (uint64_t)l * 0x100000000ull + b);
+                mulv[idx] = mu;
+                mulv[n + idx] = lv;
+            }
+            e = eps ? eps[(int64_t)b * L + l] : ov_randn(seed, rng_off, eps_stream, (uint64_t)l * 0x100000000ull + b);
+            z = mu + e * expf(0.5f * lv);
+            kl += 1.f + lv - mu * mu - expf(lv);
+        } else {
+            mulv[idx] = 0.f;
+            mulv[n + idx] = 0.f;
+        }
+        if (epsw) epsw[idx] = e;
+        zrows[idx] = z;
+    }
+    if (write_kl) {
+        __shared__ float red[4];
+        kl = ov_wave_sum(kl);
+        if (ov_lane() == 0) red[threadIdx.x >> 6] = kl;
+        __syncthreads();
+        if (threadIdx.x == 0) kl_part[blockIdx.x] = -0.5f * (red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// dmu = dz + kc*mu ; dlv = dz * eps * 0.5 * sigma + 0.5*kc*(exp(lv) - 1), then back through z_drop
+__global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mulv,
+                                                           const float* __restrict__ epsw, float* __restrict__ dmulv,
+                                                           int L, int B, int ldb, float kc, float z_drop, uint64_t seed,
+                                                           uint64_t rng_off) {
+    const int64_t n = (int64_t)L * ldb;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int l = (int)(idx / ldb), b = (int)(idx % ldb);
+        float dmu = 0.f, dlv = 0.f;
+        if (b < B) {
+            const float mu = mulv[idx], lv = mulv[n + idx], g = dz[idx], e = epsw[idx];
+            dmu = g + kc * mu;
+            dlv = g * e * 0.5f * expf(0.5f * lv) + 0.5f * kc * (expf(lv) - 1.f);
+            if (z_drop > 0.f) {
+                dmu *= ov_dropout_scale(z_drop, seed, rng_off, OV_RNG_ZDROP_MU, (uint64_t)l * 0x100000000ull + b);
+                dlv *= ov_dropout_scale(z_drop, seed, rng_off, OV_RNG_ZDROP_LV, (uint64_t)l * 0x100000000ull + b);
+            }
+        }
+        dmulv[idx] = dmu;
+        dmulv[n + idx] = dlv;
+    }
+}
+
+// =================================================================================================
+// Ontology decoder: level-scheduled gather-SpMM over the packed masks
+// =================================================================================================
+// Forward, one wave per (node, 64*VEC batch columns):
+//   ACT[n, :] = bias[n] + sum_k vals[k] * ACT[colidx[k], :]           (modules.py:309, 311)
+// GENE variant (the last layer): the reconstruction never goes to HBM in training; the epilogue
+// forms d = recon - x, writes dL/drecon = 2 d into D[n, :] and block partials of sum d^2
+// (vae_model.py:125), or stores recon sample-major for inference.
+template <int VEC>
+struct OvVecT;
+template <> struct OvVecT<1> { typedef float T; };
+template <> struct OvVecT<2> { typedef float __attribute__((ext_vector_type(2))) T; };
+template <> struct OvVecT<4> { typedef f32x4 T; };
+
+template <int VEC>
+__device__ __forceinline__ void ov_ldv(const float* p, float (&v)[VEC]) {
+    typedef typename OvVecT<VEC>::T VT;
+    const VT t = *reinterpret_cast<const VT*>(p);
+    if constexpr (VEC == 1) v[0] = t;
+    else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = t[j];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void ov_stv(float* p, const float (&v)[VEC]) {
+    typedef typename OvVecT<VEC>::T VT;
+    VT t;
+    if constexpr (VEC == 1) t = v[0];
+    else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) t[j] = v[j];
+    }
+    *reinterpret_cast<VT*>(p) = t;
+}
+
+// GENE: 0 = term level (write ACT), 1 = gene level training (D + loss partials), 2 = gene level
+// inference (recon sample-major to rec_out)
+template <int VEC, int GENE>
+__global__ __launch_bounds__(256) void ov_dec_fwd_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                        const float* __restrict__ vals, const float* __restrict__ bias,
+                                                        float* __restrict__ act, int node_begin, int node_end, int B, int ldb,
+                                                        const float* __restrict__ x, const int32_t* __restrict__ xidx, int G,
+                                                        float* __restrict__ d, float* __restrict__ rec_part,
+                                                        float* __restrict__ rec_out, int64_t rec_ld, int C) {
+    const int node = node_begin + blockIdx.x * 4 + ov_wave_id();
+    const int lane = ov_lane();
+    const int b0 = blockIdx.y * (64 * VEC) + lane * VEC;
+    float sq = 0.f;
+    if (node < node_end) {
+        float acc[VEC];
+        const float bv = bias[node];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = bv;
+        const int k0 = rowptr[node], k1 = rowptr[node + 1];
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+            const int c0 = colidx[k], c1 = colidx[k + 1], c2 = colidx[k + 2], c3 = colidx[k + 3];
+            const float w0 = vals[k], w1 = vals[k + 1], w2 = vals[k + 2], w3 = vals[k + 3];
+            ov_ldv<VEC>(act + (int64_t)c0 * ldb + b0, v0);
+            ov_ldv<VEC>(act + (int64_t)c1 * ldb + b0, v1);
+            ov_ldv<VEC>(act + (int64_t)c2 * ldb + b0, v2);
+            ov_ldv<VEC>(act + (int64_t)c3 * ldb + b0, v3);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                acc[j] += w0 * v0[j];
+                acc[j] += w1 * v1[j];
+                acc[j] += w2 * v2[j];
+                acc[j] += w3 * v3[j];
+            }
+        }
+        for (; k < k1; ++k) {
+            float v0[VEC];
+            const int c0 = colidx[k];
+            const float w0 = vals[k];
+            ov_ldv<VEC>(act + (int64_t)c0 * ldb + b0, v0);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += w0 * v0[j];
+        }
+        if (GENE == 0) {
+            ov_stv<VEC>(act + (int64_t)node * ldb + b0, acc);
+        } else if (GENE == 1) {
+            const int g = node - C;
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int b = b0 + j;
+                float dv = 0.f;
+                if (b < B) {
+                    const int64_t r = xidx ? (int64_t)xidx[b] : (int64_t)b;
+                    dv = acc[j] - x[r * G + g];
+                    sq += dv * dv;
+                }
+                o[j] = 2.f * dv;
+            }
+            ov_stv<VEC>(d + (int64_t)node * ldb + b0, o);
+        } else {
+            const int g = node - C;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int b = b0 + j;
+                if (b < B) rec_out[(int64_t)b * rec_ld + g] = acc[j];
+            }
+        }
+    }
+    if (GENE == 1) {
+        __shared__ float red[4];
+        sq = ov_wave_sum(sq);
+        if (lane == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) rec_part[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+// Backward data, one wave per (panel node of the level, batch chunk), CSC gather:
+//   D[p, :] = sum_q vals[csc_k[q]] * D[csc_row[q], :]
+template <int VEC>
+__global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_row,
+                                                        const int32_t* __restrict__ csc_k, const float* __restrict__ vals,
+                                                        float* __restrict__ d, int node_begin, int node_end, int ldb) {
+    const int node = node_begin + blockIdx.x * 4 + ov_wave_id();
+    if (node >= node_end) return;
+    const int b0 = blockIdx.y * (64 * VEC) + ov_lane() * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    const int q0 = cscptr[node], q1 = cscptr[node + 1];
+    int q = q0;
+    for (; q + 4 <= q1; q += 4) {
+        float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+        const int r0 = csc_row[q], r1 = csc_row[q + 1], r2 = csc_row[q + 2], r3 = csc_row[q + 3];
+        const float w0 = vals[csc_k[q]], w1 = vals[csc_k[q + 1]], w2 = vals[csc_k[q + 2]], w3 = vals[csc_k[q + 3]];
+        ov_ldv<VEC>(d + (int64_t)r0 * ldb + b0, v0);
+        ov_ldv<VEC>(d + (int64_t)r1 * ldb + b0, v1);
+        ov_ldv<VEC>(d + (int64_t)r2 * ldb + b0, v2);
+        ov_ldv<VEC>(d + (int64_t)r3 * ldb + b0, v3);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            acc[j] += w0 * v0[j];
+            acc[j] += w1 * v1[j];
+            acc[j] += w2 * v2[j];
+            acc[j] += w3 * v3[j];
+        }
+    }
+    for (; q < q1; ++q) {
+        float v0[VEC];
+        const int r0 = csc_row[q];
+        const float w0 = vals[csc_k[q]];
+        ov_ldv<VEC>(d + (int64_t)r0 * ldb + b0, v0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += w0 * v0[j];
+    }
+    ov_stv<VEC>(d + (int64_t)node * ldb + b0, acc);
+}
+
+// Weight gradient at mask positions only (SDDMM) + fused AdamW + clamp(0), one wave per row node:
+//   g_k = sum_b D[n, b] * ACT[colidx[k], b];   gb = sum_b D[n, b]
+// The padded batch columns of D are zero by construction, so no masking is needed in the dots.
+// The 64 lanes then update 64 consecutive packed weights at once (coalesced w, m, v traffic).
+__global__ __launch_bounds__(256) void ov_dec_wgrad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                          const float* __restrict__ act, const float* __restrict__ d,
+                                                          float* __restrict__ vals, float* __restrict__ mvals,
+                                                          float* __restrict__ vvals, float* __restrict__ gvals,
+                                                          float* __restrict__ bias, float* __restrict__ mbias,
+                                                          float* __restrict__ vbias, float* __restrict__ gbias, int nrows,
+                                                          int first_term_node, int n_term_rows, int C, int ldb,
+                                                          int apply_update, OvAdam adam) {
+    const int r = blockIdx.x * 4 + ov_wave_id();
+    if (r >= nrows) return;
+    // rows are the term-feature nodes that have a layer above them, then the gene nodes
+    const int node = r < n_term_rows ? first_term_node + r : C + (r - n_term_rows);
+    const int lane = ov_lane();
+    const float* dr = d + (int64_t)node * ldb;
+    const int k0 = rowptr[node], k1 = rowptr[node + 1];
+    float gb = 0.f;
+    for (int b = lane; b < ldb; b += 64) gb += dr[b];
+    gb = ov_wave_sum(gb);
+    for (int kb = k0; kb < k1; kb += 64) {
+        const int cnt = min(64, k1 - kb);
+        float mine = 0.f;
+        for (int j = 0; j < cnt; ++j) {
+            const int c = colidx[kb + j];
+            const float* ar = act + (int64_t)c * ldb;
+            float s = 0.f;
+            for (int b = lane; b < ldb; b += 64) s += dr[b] * ar[b];
+            s = ov_wave_sum(s);
+            if (lane == j) mine = s;
+        }
+        if (lane < cnt) {
+            const int k = kb + lane;
+            if (apply_update) {
+                float w = vals[k], m = mvals[k], v = vvals[k];
+                ov_adamw(w, m, v, mine, adam, true);
+                vals[k] = w; mvals[k] = m; vvals[k] = v;
+            } else {
+                gvals[k] = mine;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (apply_update) {
+            float w = bias[node], m = mbias[node], v = vbias[node];
+            ov_adamw(w, m, v, gb, adam, false);
+            bias[node] = w; mbias[node] = m; vbias[node] = v;
+        } else {
+            gbias[node] = gb;
+        }
+    }
+}
+
+// =================================================================================================
+// Small kernels
+// =================================================================================================
+// row sums of a feature-major matrix (+ AdamW): bias gradients of the heads
+__global__ __launch_bounds__(256) void ov_rowsum_adamw_kernel(const float* __restrict__ src, int rows, int ldb,
+                                                             float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                             float* __restrict__ g, int apply_update, OvAdam adam) {
+    const int r = blockIdx.x * 4 + ov_wave_id();
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int b = ov_lane(); b < ldb; b += 64) s += src[(int64_t)r * ldb + b];
+    s = ov_wave_sum(s);
+    if (ov_lane() == 0) {
+        if (apply_update) {
+            float ww = w[r], mm = m[r], vv = v[r];
+            ov_adamw(ww, mm, vv, s, adam, false);
+            w[r] = ww; m[r] = mm; v[r] = vv;
+        } else {
+            g[r] = s;
+        }
+    }
+}
+
+// deterministic final reduction of the block partials; loss = rec + kl_coeff * kl (vae_model.py:129)
+__global__ __launch_bounds__(1024) void ov_loss_finalize_kernel(const float* __restrict__ rec_part, int nrec,
+                                                               const float* __restrict__ kl_part, int nkl, float kc,
+                                                               float* __restrict__ out) {
+    __shared__ double red[2][16];
+    double r = 0.0, k = 0.0;
+    for (int i = threadIdx.x; i < nrec; i += 1024) r += (double)rec_part[i];
+    for (int i = threadIdx.x; i < nkl; i += 1024) k += (double)kl_part[i];
+    r = ov_wave_sum_d(r);
+    k = ov_wave_sum_d(k);
+    if (ov_lane() == 0) {
+        red[0][threadIdx.x >> 6] = r;
+        red[1][threadIdx.x >> 6] = k;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double rr = 0.0, kk = 0.0;
+        for (int i = 0; i < 16; ++i) { rr += red[0][i]; kk += red[1][i]; }
+        const float rf = (float)rr, kf = (float)kk;
+        out[0] = rf;
+        out[1] = kf;
+        out[2] = rf + kc * kf;
+    }
+}
+
+// flat AdamW over [0, n) with clamp(0) inside [c0, c1)
+__global__ __launch_bounds__(256) void ov_adamw_flat_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
+                                                           const float* __restrict__ Gr, int64_t n, int64_t c0, int64_t c1,
+                                                           OvAdam adam) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float w = P[i], m = M[i], v = V[i];
+        ov_adamw(w, m, v, Gr[i], adam, i >= c0 && i < c1);
+        P[i] = w; M[i] = m; V[i] = v;
+    }
+}
+
+// feature-major [F, ldb] -> sample-major [B, ld_out] (32x32 LDS tile)
+__global__ __launch_bounds__(256) void ov_transpose_out_kernel(const float* __restrict__ src, int F, int B, int ldb,
+                                                              float* __restrict__ dst, int64_t ld_out) {
+    __shared__ float tile[32][33];
+    const int f0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int f = f0 + j, b = b0 + tx;
+        tile[j][tx] = (f < F && b < B) ? src[(int64_t)f * ldb + b] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int b = b0 + j, f = f0 + tx;
+        if (f < F && b < B) dst[(int64_t)b * ld_out + f] = tile[tx][j];
+    }
+}
+
+// sample-major z [B, L] -> feature-major panel rows
+__global__ __launch_bounds__(256) void ov_transpose_in_kernel(const float* __restrict__ src, int F, int B, int ldb,
+                                                             float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int f0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int b = b0 + j, f = f0 + tx;
+        tile[j][tx] = (f < F && b < B) ? src[(int64_t)b * F + f] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int f = f0 + j, b = b0 + tx;
+        if (f < F && b < ldb) dst[(int64_t)f * ldb + b] = tile[tx][j];
+    }
+}
+
+// nu-mean of the panel rows of one level into sample-major activities (vae_model.py:297, 317):
+// out[b, t0 + j] = (ACT[n0 + j*nu, b] + ... + ACT[n0 + j*nu + nu - 1, b]) / nu
+__global__ __launch_bounds__(256) void ov_act_out_kernel(const float* __restrict__ act, int n0, int nterms, int nu, int B,
+                                                        int ldb, float* __restrict__ out, int64_t ld_out, int t0) {
+    __shared__ float tile[32][33];
+    const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int j = j0 + jj, b = b0 + tx;
+        float s = 0.f;
+        if (j < nterms && b < B) {
+            for (int a = 0; a < nu; ++a) s += act[(int64_t)(n0 + j * nu + a) * ldb + b];
+            s = s / (float)nu;
+        }
+        tile[jj][tx] = s;
+    }
+    __syncthreads();
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int b = b0 + jj, j = j0 + tx;
+        if (j < nterms && b < B) out[(int64_t)b * ld_out + t0 + j] = tile[tx][jj];
+    }
+}
+
+__global__ void ov_compose_order_kernel(const int32_t* __restrict__ in, const int64_t* __restrict__ perm,
+                                        int32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[perm[i]];
+}
+
+__global__ __launch_bounds__(256) void ov_gather_rows_kernel(const float* __restrict__ X, int64_t ld, const int32_t* __restrict__ idx,
+                                                            int G, float* __restrict__ out) {
+    const int b = blockIdx.x;
+    const float* src = X + (int64_t)idx[b] * ld;
+    float* dst = out + (int64_t)b * G;
+    for (int g = threadIdx.x; g < G; g += 256) dst[g] = src[g];
+}
+
+__global__ void ov_vals_to_dense_kernel(const float* __restrict__ vals, const int32_t* __restrict__ er,
+                                        const int32_t* __restrict__ ec, int64_t k0, int64_t k1, float* __restrict__ dense,
+                                        int64_t ld) {
+    const int64_t k = k0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < k1) dense[(int64_t)er[k] * ld + ec[k]] = vals[k];
+}
+__global__ void ov_dense_to_vals_kernel(const float* __restrict__ dense, int64_t ld, const int32_t* __restrict__ er,
+                                        const int32_t* __restrict__ ec, int64_t k0, int64_t k1, float* __restrict__ vals) {
+    const int64_t k = k0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < k1) vals[k] = dense[(int64_t)er[k] * ld + ec[k]];
+}
+
+// =================================================================================================
+// Host-side launch helpers
+// =================================================================================================
+static inline OvAdam ov_adam_from(const ontovae_adamw_t* o) {
+    OvAdam a{};
+    if (o) {
+        a.decay_mul = o->decay_mul; a.one_m_beta1 = o->one_m_beta1; a.beta2 = o->beta2; a.one_m_beta2 = o->one_m_beta2;
+        a.step_size = o->step_size; a.bc2_sqrt = o->bc2_sqrt; a.eps = o->eps;
+    }
+    return a;
+}
+
+static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
+    if (!c) { ontovae_set_error("ctx is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_dims_t& d = c->dims;
+    if (d.G < 1 || d.L < 1 || d.C < d.L || d.K < 1 || d.nu < 1 || d.nnz < 0) {
+        ontovae_set_error("ctx: bad dims G=%d L=%d C=%d K=%d nu=%d", d.G, d.L, d.C, d.K, d.nu);
+        return ONTOVAE_EINVAL;
+    }
+    if (!c->P || !c->rowptr || !c->colidx || !c->cscptr || !c->csc_row || !c->csc_k || !c->level_begin || !c->level_end ||
+        !c->workspace || !c->bn_rmean || !c->bn_rvar || !c->bn_nbt) {
+        ontovae_set_error("ctx: a required pointer is NULL");
+        return ONTOVAE_EINVAL;
+    }
+    if (need_opt && (!c->M || !c->V)) { ontovae_set_error("ctx: optimizer state (M, V) is NULL"); return ONTOVAE_EINVAL; }
+    if (B < 1 || B > c->max_batch) {
+        ontovae_set_error("batch size %d outside [1, max_batch=%d]", B, c->max_batch);
+        return ONTOVAE_EINVAL;
+    }
+    if (c->workspace_bytes < ov_carve(d, c->max_batch, nullptr, nullptr)) {
+        ontovae_set_error("workspace too small: %lld < %lld bytes", (long long)c->workspace_bytes,
+                          (long long)ov_carve(d, c->max_batch, nullptr, nullptr));
+        return ONTOVAE_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(c->workspace) & 255) || (reinterpret_cast<uintptr_t>(c->P) & 15)) {
+        ontovae_set_error("ctx: workspace must be 256-B aligned and P 16-B aligned");
+        return ONTOVAE_EINVAL;
+    }
+    return ONTOVAE_OK;
+}
+
+template <int MT, int NT, bool A_KC, bool B_KC, int EPI>
+static int ov_launch_gemm(const OvGemm& g, int S, bool vec, hipStream_t st) {
+    dim3 grid((g.N + 64 * NT - 1) / (64 * NT), (g.M + 64 * MT - 1) / (64 * MT), S);
+    if (vec) hipLaunchKernelGGL((ov_gemm_kernel<MT, NT, A_KC, B_KC, true, EPI>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((ov_gemm_kernel<MT, NT, A_KC, B_KC, false, EPI>), grid, dim3(256), 0, st, g);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+static inline bool ov_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct OvStep {
+    const ontovae_ctx_t* c;
+    OvWs ws;
+    int B, ldb, vec, nchunk;
+    hipStream_t st;
+    const float* x;
+    const int32_t* xidx;
+    int64_t xld;
+};
+
+// x W0^T -> split-K slabs  (modules.py:46)
+static int ov_enc_gemm(OvStep& s, int* S_out) {
+    const ontovae_dims_t& d = s.c->dims;
+    const int S = ov_enc_splitk(d.L, s.B, d.G);
+    int kchunk = (d.G + S - 1) / S;
+    kchunk = (kchunk + 7) / 8 * 8;
+    const int Seff = (d.G + kchunk - 1) / kchunk;
+    OvGemm g{};
+    g.M = d.L; g.N = s.B; g.K = d.G;
+    g.A = s.c->P + s.c->lay.W0; g.lda = d.G;
+    g.B = s.x; g.ldb = s.xld; g.bgather = s.xidx;
+    g.C = s.ws.slab; g.ldc = s.ldb; g.slab_stride = (int64_t)d.L * s.ldb; g.kchunk = kchunk;
+    const bool vec = (d.G % 4 == 0) && (s.xld % 4 == 0) && ov_al16(g.A) && ov_al16(g.B);
+    *S_out = Seff;
+    return ov_launch_gemm<1, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
+}
+
+static int ov_bn_fwd(OvStep& s, int S, int mode, int Bglobal, float* stats, uint64_t rng_off) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    hipLaunchKernelGGL(ov_bn_fwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb,
+                       c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, c->bn_nbt,
+                       s.ws.xhat, s.ws.a, s.ws.bn_mean, s.ws.bn_invstd, stats, d.L, s.B, Bglobal, s.ldb, mode, c->drop, c->seed,
+                       rng_off);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+// heads: [mu; log_var] = Wh a + bh  (modules.py:57, 62), feature-major
+static int ov_heads_fwd(OvStep& s) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    OvGemm g{};
+    g.M = 2 * d.L; g.N = s.B; g.K = d.L;
+    g.A = c->P + c->lay.Wh; g.lda = d.L;
+    g.B = s.ws.a; g.ldb = s.ldb; g.bgather = nullptr;
+    g.C = s.ws.mulv; g.ldc = s.ldb; g.kchunk = (d.L + 7) / 8 * 8;
+    g.bias = c->P + c->lay.bh;
+    const bool vec = (d.L % 4 == 0) && ov_al16(g.A);
+    return ov_launch_gemm<1, 1, true, false, OV_EPI_BIAS>(g, 1, vec, s.st);
+}
+
+static int ov_reparam(OvStep& s, const float* eps, int train, uint64_t rng_off, uint32_t eps_stream, int write_kl, int* nkl) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    const int64_t n = (int64_t)d.L * s.ldb;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
+    float* zrows = s.ws.act + (int64_t)(d.C - d.L) * s.ldb;
+    hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks), dim3(256), 0, s.st, s.ws.mulv, eps, s.ws.epsw, zrows, s.ws.kl_part, d.L,
+                       s.B, s.ldb, train, c->z_drop, c->seed, rng_off, eps_stream, write_kl);
+    OV_LAUNCH_CHECK();
+    if (nkl) *nkl = blocks;
+    return ONTOVAE_OK;
+}
+
+template <int GENE>
+static int ov_dec_fwd_level(OvStep& s, int nb, int ne, float* rec_out, int64_t rec_ld) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    if (ne <= nb) return ONTOVAE_OK;
+    dim3 grid((ne - nb + 3) / 4, s.nchunk);
+    const float* vals = c->P + c->lay.dec_vals;
+    const float* bias = c->P + c->lay.dec_bias;
+#define OV_DF(V)                                                                                                        \
+    hipLaunchKernelGGL((ov_dec_fwd_kernel<V, GENE>), grid, dim3(256), 0, s.st, c->rowptr, c->colidx, vals, bias, s.ws.act, \
+                       nb, ne, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C)
+    if (s.vec == 1) OV_DF(1); else if (s.vec == 2) OV_DF(2); else OV_DF(4);
+#undef OV_DF
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+static int ov_dec_forward_terms(OvStep& s) {
+    const ontovae_dims_t& d = s.c->dims;
+    for (int lvl = 1; lvl < d.K; ++lvl) {
+        int rc = ov_dec_fwd_level<0>(s, s.c->level_begin[lvl], s.c->level_end[lvl], nullptr, 0);
+        if (rc) return rc;
+    }
+    return ONTOVAE_OK;
+}
+
+static int ov_dec_bwd_level(OvStep& s, int nb, int ne) {
+    const ontovae_ctx_t* c = s.c;
+    if (ne <= nb) return ONTOVAE_OK;
+    dim3 grid((ne - nb + 3) / 4, s.nchunk);
+    const float* vals = c->P + c->lay.dec_vals;
+#define OV_DB(V) hipLaunchKernelGGL((ov_dec_bwd_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_row, c->csc_k, vals, s.ws.d, nb, ne, s.ldb)
+    if (s.vec == 1) OV_DB(1); else if (s.vec == 2) OV_DB(2); else OV_DB(4);
+#undef OV_DB
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+static int ov_loss_finalize(OvStep& s, int nrec, int nkl, float kc, float* loss_out) {
+    hipLaunchKernelGGL(ov_loss_finalize_kernel, dim3(1), dim3(1024), 0, s.st, s.ws.rec_part, nrec, s.ws.kl_part, nkl, kc, loss_out);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int B, void* stream, OvStep* s) {
+    s->c = ctx;
+    ov_carve(ctx->dims, ctx->max_batch, ctx->workspace, &s->ws);
+    s->B = B;
+    s->ldb = ov_ldb(B);
+    s->vec = ov_vec(B);
+    s->nchunk = (s->ldb + 64 * s->vec - 1) / (64 * s->vec);
+    s->st = reinterpret_cast<hipStream_t>(stream);
+    s->x = x;
+    s->xidx = xidx;
+    s->xld = ctx->dims.G;
+    return ONTOVAE_OK;
+}
+
+// encoder (eval or fused-train) + heads + reparam: leaves mu/lv in ws.mulv, z in the panel
+static int ov_encode(OvStep& s, const float* eps, int train, uint64_t rng_off, uint32_t eps_stream, int write_kl, int* nkl) {
+    int S = 1, rc;
+    if ((rc = ov_enc_gemm(s, &S))) return rc;
+    if ((rc = ov_bn_fwd(s, S, train ? 1 : 0, s.B, nullptr, rng_off))) return rc;
+    if ((rc = ov_heads_fwd(s))) return rc;
+    return ov_reparam(s, eps, train, rng_off, eps_stream, write_kl, nkl);
+}
+
+static int ov_transpose_out(OvStep& s, const float* src, int F, float* dst, int64_t ld) {
+    dim3 grid((F + 31) / 32, (s.B + 31) / 32);
+    hipLaunchKernelGGL(ov_transpose_out_kernel, grid, dim3(256), 0, s.st, src, F, s.B, s.ldb, dst, ld);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+// =================================================================================================
+// C ABI: forward / eval / inference
+// =================================================================================================
+extern "C" int ontovae_forward(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
+                               uint64_t rng_offset, int32_t train, float* recon, float* mu, float* log_var, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!x) { ontovae_set_error("forward: x is NULL"); return ONTOVAE_EINVAL; }
+    if (train && B < 2) { ontovae_set_error("forward: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, x, xidx, B, stream, &s);
+    const ontovae_dims_t& d = ctx->dims;
+    if ((rc = ov_encode(s, eps, train, rng_offset, OV_RNG_EPS, 0, nullptr))) return rc;
+    if (mu && (rc = ov_transpose_out(s, s.ws.mulv, d.L, mu, d.L))) return rc;
+    if (log_var && (rc = ov_transpose_out(s, s.ws.mulv + (int64_t)d.L * s.ldb, d.L, log_var, d.L))) return rc;
+    if (recon) {
+        if ((rc = ov_dec_forward_terms(s))) return rc;
+        if ((rc = ov_dec_fwd_level<2>(s, d.C, d.C + d.G, recon, d.G))) return rc;
+    }
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
+                                 uint64_t rng_offset, float kl_coeff, float* loss_out, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!x || !loss_out) { ontovae_set_error("eval_step: x or loss_out is NULL"); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, x, xidx, B, stream, &s);
+    const ontovae_dims_t& d = ctx->dims;
+    int nkl = 0;
+    if ((rc = ov_encode(s, eps, 0, rng_offset, OV_RNG_EPS, 1, &nkl))) return rc;
+    if ((rc = ov_dec_forward_terms(s))) return rc;
+    if ((rc = ov_dec_fwd_level<1>(s, d.C, d.C + d.G, nullptr, 0))) return rc;
+    return ov_loss_finalize(s, ((d.G + 3) / 4) * s.nchunk, nkl, kl_coeff, loss_out);
+}
+
+static int ov_act_out(OvStep& s, int lvl_from, int lvl_to, float* act_out, int64_t act_ld) {
+    const ontovae_dims_t& d = s.c->dims;
+    int t0 = 0;
+    for (int lvl = 0; lvl < d.K; ++lvl) {
+        const int n0 = s.c->level_begin[lvl];
+        const int nterms = (s.c->level_end[lvl] - n0) / d.nu;
+        if (lvl >= lvl_from && lvl < lvl_to && nterms > 0) {
+            dim3 grid((nterms + 31) / 32, (s.B + 31) / 32);
+            hipLaunchKernelGGL(ov_act_out_kernel, grid, dim3(256), 0, s.st, s.ws.act, n0, nterms, d.nu, s.B, s.ldb, act_out, act_ld, t0);
+            OV_LAUNCH_CHECK();
+        }
+        t0 += nterms;
+    }
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps1,
+                                 const float* eps2, uint64_t rng_offset, float* act_out, int64_t act_ld, float* rec_out,
+                                 int64_t rec_ld, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!x) { ontovae_set_error("pass_data: x is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_dims_t& d = ctx->dims;
+    if ((act_out && act_ld < d.T) || (rec_out && rec_ld < d.G)) { ontovae_set_error("pass_data: output leading dimension too small"); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, x, xidx, B, stream, &s);
+    // The reference runs the encoder twice (get_embedding, then forward); in eval mode both runs give
+    // the same mu / log_var, so one encoder pass and two reparameterisations are identical.
+    if ((rc = ov_encode(s, eps1, 0, rng_offset, OV_RNG_EPS, 0, nullptr))) return rc;
+    if (act_out && (rc = ov_act_out(s, 0, 1, act_out, act_ld))) return rc;          // z part from draw #1
+    if ((rc = ov_reparam(s, eps2, 0, rng_offset, OV_RNG_EPS2, 0, nullptr))) return rc;  // draw #2 feeds the decoder
+    if ((rc = ov_dec_forward_terms(s))) return rc;
+    if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld))) return rc;
+    if (rec_out && (rc = ov_dec_fwd_level<2>(s, d.C, d.C + d.G, rec_out, rec_ld))) return rc;
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z, int32_t B, float* act_out, int64_t act_ld,
+                                       float* rec_out, int64_t rec_ld, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!z) { ontovae_set_error("decoder_forward: z is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_dims_t& d = ctx->dims;
+    if ((act_out && act_ld < d.T) || (rec_out && rec_ld < d.G)) { ontovae_set_error("decoder_forward: output leading dimension too small"); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, nullptr, nullptr, B, stream, &s);
+    dim3 grid((d.L + 31) / 32, (s.ldb + 31) / 32);
+    hipLaunchKernelGGL(ov_transpose_in_kernel, grid, dim3(256), 0, s.st, z, d.L, B, s.ldb, s.ws.act + (int64_t)(d.C - d.L) * s.ldb);
+    OV_LAUNCH_CHECK();
+    if ((rc = ov_dec_forward_terms(s))) return rc;
+    if (act_out && (rc = ov_act_out(s, 0, d.K, act_out, act_ld))) return rc;
+    if (rec_out && (rc = ov_dec_fwd_level<2>(s, d.C, d.C + d.G, rec_out, rec_ld))) return rc;
+    return ONTOVAE_OK;
+}
+
+// =================================================================================================
+// C ABI: training
+// =================================================================================================
+// Everything after the encoder forward: decoder, ELBO, full backward, weight gradients.
+// bn_mode: 1 = fused BN backward (single GPU), 2 = stop after the DP phase-1 BN partial sums.
+static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float kc, const ontovae_adamw_t* opt, int apply,
+                           float* loss_out, int bn_mode, float* bn_bwd_stats, int Bglobal) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    const ontovae_layout_t& lay = c->lay;
+    const OvAdam adam = ov_adam_from(opt);
+    int rc, nkl = 0;
+    if ((rc = ov_heads_fwd(s))) return rc;
+    if ((rc = ov_reparam(s, eps, 1, rng_off, OV_RNG_EPS, 1, &nkl))) return rc;
+    if ((rc = ov_dec_forward_terms(s))) return rc;
+    if ((rc = ov_dec_fwd_level<1>(s, d.C, d.C + d.G, nullptr, 0))) return rc;
+    for (int lvl = d.K - 1; lvl >= 0; --lvl)
+        if ((rc = ov_dec_bwd_level(s, c->level_begin[lvl], c->level_end[lvl]))) return rc;
+    if ((rc = ov_loss_finalize(s, ((d.G + 3) / 4) * s.nchunk, nkl, kc, loss_out))) return rc;
+    // decoder weight gradients (+ AdamW + clamp)
+    {
+        const int n_term_rows = d.C - d.L;
+        const int nrows = n_term_rows + d.G;
+        float* G_ = c->Gr;
+        hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s.st, c->rowptr, c->colidx, s.ws.act, s.ws.d,
+                           c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
+                           G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
+                           c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, nrows, 0, n_term_rows, d.C, s.ldb,
+                           apply, adam);
+        OV_LAUNCH_CHECK();
+    }
+    // latent backward
+    {
+        const int64_t n = (int64_t)d.L * s.ldb;
+        const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
+        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(blocks), dim3(256), 0, s.st, s.ws.d + (int64_t)(d.C - d.L) * s.ldb, s.ws.mulv,
+                           s.ws.epsw, s.ws.dmulv, d.L, s.B, s.ldb, kc, c->z_drop, c->seed, rng_off);
+        OV_LAUNCH_CHECK();
+    }
+    // da = Wh^T dmulv  (before Wh is updated)
+    {
+        OvGemm g{};
+        g.M = d.L; g.N = s.B; g.K = 2 * d.L;
+        g.A = c->P + lay.Wh; g.lda = d.L;          // A(m=l, k=j) = Wh[j*L + l]
+        g.B = s.ws.dmulv; g.ldb = s.ldb;
+        g.C = s.ws.da; g.ldc = s.ldb; g.kchunk = (2 * d.L + 7) / 8 * 8;
+        if ((rc = ov_launch_gemm<1, 1, false, false, OV_EPI_STORE>(g, 1, false, s.st))) return rc;
+    }
+    // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv)
+    {
+        OvGemm g{};
+        g.M = 2 * d.L; g.N = d.L; g.K = s.B;
+        g.A = s.ws.dmulv; g.lda = s.ldb;
+        g.B = s.ws.a; g.ldb = s.ldb;
+        g.ldc = d.L; g.kchunk = (s.B + 7) / 8 * 8;
+        g.adam = adam;
+        if (apply) {
+            g.C = c->P + lay.Wh; g.Pm = c->M + lay.Wh; g.Pv = c->V + lay.Wh;
+            if ((rc = ov_launch_gemm<1, 1, true, true, OV_EPI_ADAMW>(g, 1, true, s.st))) return rc;
+        } else {
+            g.C = c->Gr + lay.Wh;
+            if ((rc = ov_launch_gemm<1, 1, true, true, OV_EPI_STORE>(g, 1, true, s.st))) return rc;
+        }
+        hipLaunchKernelGGL(ov_rowsum_adamw_kernel, dim3((2 * d.L + 3) / 4), dim3(256), 0, s.st, s.ws.dmulv, 2 * d.L, s.ldb,
+                           c->P + lay.bh, c->M ? c->M + lay.bh : nullptr, c->V ? c->V + lay.bh : nullptr,
+                           c->Gr ? c->Gr + lay.bh : nullptr, apply, adam);
+        OV_LAUNCH_CHECK();
+    }
+    // BN backward
+    {
+        float* Gr = c->Gr;
+        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd,
+                           c->P + lay.gamma, c->P + lay.beta, c->P + lay.b0, c->M ? c->M + lay.gamma : nullptr,
+                           c->M ? c->M + lay.beta : nullptr, c->M ? c->M + lay.b0 : nullptr, c->V ? c->V + lay.gamma : nullptr,
+                           c->V ? c->V + lay.beta : nullptr, c->V ? c->V + lay.b0 : nullptr, Gr ? Gr + lay.gamma : nullptr,
+                           Gr ? Gr + lay.beta : nullptr, Gr ? Gr + lay.b0 : nullptr, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L,
+                           s.B, Bglobal, s.ldb, bn_mode, apply, adam, c->drop, c->seed, rng_off);
+        OV_LAUNCH_CHECK();
+    }
+    return ONTOVAE_OK;
+}
+
+// dW0 = dh x (+ AdamW)   (gradient of modules.py:46)
+static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    OvGemm g{};
+    g.M = d.L; g.N = d.G; g.K = s.B;
+    g.A = s.ws.dh; g.lda = s.ldb;
+    g.B = s.x; g.ldb = s.xld; g.bgather = s.xidx;     // B(k=b, n=g) = X[row(b) * G + g]
+    g.ldc = d.G; g.kchunk = (s.B + 7) / 8 * 8;
+    g.adam = ov_adam_from(opt);
+    if (apply) {
+        g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
+        return ov_launch_gemm<1, 1, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
+    }
+    g.C = c->Gr + c->lay.W0;
+    return ov_launch_gemm<1, 1, true, false, OV_EPI_STORE>(g, 1, true, s.st);
+}
+
+extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
+                                  uint64_t rng_offset, float kl_coeff, const ontovae_adamw_t* opt, int32_t apply_update,
+                                  float* loss_out, void* stream) {
+    int rc = ov_check_ctx(ctx, B, apply_update != 0);
+    if (rc) return rc;
+    if (!x || !loss_out) { ontovae_set_error("train_step: x or loss_out is NULL"); return ONTOVAE_EINVAL; }
+    if (apply_update && !opt) { ontovae_set_error("train_step: opt is NULL"); return ONTOVAE_EINVAL; }
+    if (!apply_update && !ctx->Gr) { ontovae_set_error("train_step: gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+    if (B < 2) { ontovae_set_error("train_step: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, x, xidx, B, stream, &s);
+    int S = 1;
+    if ((rc = ov_enc_gemm(s, &S))) return rc;
+    if ((rc = ov_bn_fwd(s, S, 1, B, nullptr, rng_offset))) return rc;
+    if ((rc = ov_train_tail_a(s, eps, rng_offset, kl_coeff, opt, apply_update, loss_out, 1, nullptr, B))) return rc;
+    return ov_dw0(s, opt, apply_update);
+}
+
+extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, const float* x, const int32_t* xidx, int32_t B,
+                                     int32_t B_global, const float* eps, uint64_t rng_offset, float kl_coeff, float* bn_stats,
+                                     float* bn_bwd_stats, float* loss_out, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!x || !bn_stats || !bn_bwd_stats || !loss_out || !ctx->Gr) { ontovae_set_error("train_step_dp: a required pointer is NULL"); return ONTOVAE_EINVAL; }
+    if (B_global < 2 || B_global < B) { ontovae_set_error("train_step_dp: bad global batch %d (local %d)", B_global, B); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, x, xidx, B, stream, &s);
+    if (phase == 0) {
+        int S = 1;
+        if ((rc = ov_enc_gemm(s, &S))) return rc;
+        return ov_bn_fwd(s, S, 2, B_global, bn_stats, rng_offset);
+    } else if (phase == 1) {
+        if ((rc = ov_bn_fwd(s, 1, 3, B_global, bn_stats, rng_offset))) return rc;
+        return ov_train_tail_a(s, eps, rng_offset, kl_coeff, nullptr, 0, loss_out, 2, bn_bwd_stats, B_global);
+    } else if (phase == 2) {
+        const ontovae_dims_t& d = ctx->dims;
+        const ontovae_layout_t& lay = ctx->lay;
+        OvAdam adam{};
+        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd,
+                           ctx->P + lay.gamma, ctx->P + lay.beta, ctx->P + lay.b0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           ctx->Gr + lay.gamma, ctx->Gr + lay.beta, ctx->Gr + lay.b0, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, B,
+                           B_global, s.ldb, 3, 0, adam, ctx->drop, ctx->seed, rng_offset);
+        OV_LAUNCH_CHECK();
+        return ov_dw0(s, nullptr, 0);
+    }
+    ontovae_set_error("train_step_dp: phase %d not in {0,1,2}", phase);
+    return ONTOVAE_EINVAL;
+}
+
+extern "C" int ontovae_adamw_apply(const ontovae_ctx_t* ctx, const ontovae_adamw_t* opt, void* stream) {
+    if (!ctx || !opt || !ctx->P || !ctx->M || !ctx->V || !ctx->Gr) { ontovae_set_error("adamw_apply: a required pointer is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_layout_t& lay = ctx->lay;
+    const int64_t n = lay.total;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(ov_adamw_flat_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ctx->P, ctx->M, ctx->V,
+                       ctx->Gr, n, lay.dec_vals, lay.dec_vals + ctx->dims.nnz, ov_adam_from(opt));
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+// =================================================================================================
+// C ABI: batcher + state_dict helpers
+// =================================================================================================
+extern "C" int ontovae_compose_order(const int32_t* order_in, const int64_t* perm, int32_t* order_out, int64_t n, void* stream) {
+    if (!order_in || !perm || !order_out || n < 0 || order_in == order_out) { ontovae_set_error("compose_order: bad arguments"); return ONTOVAE_EINVAL; }
+    if (n == 0) return ONTOVAE_OK;
+    hipLaunchKernelGGL(ov_compose_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       order_in, perm, order_out, n);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_gather_rows(const float* X, int64_t ld, const int32_t* idx, int32_t B, int32_t G, float* out, void* stream) {
+    if (!X || !idx || !out || B < 0 || G < 1 || ld < G) { ontovae_set_error("gather_rows: bad arguments"); return ONTOVAE_EINVAL; }
+    if (B == 0) return ONTOVAE_OK;
+    hipLaunchKernelGGL(ov_gather_rows_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, ld, idx, G, out);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_vals_to_dense(const float* vals, const int32_t* entry_row, const int32_t* entry_col, int64_t k0, int64_t k1,
+                                     float* dense, int64_t ld, void* stream) {
+    if (!vals || !entry_row || !entry_col || !dense || k1 < k0) { ontovae_set_error("vals_to_dense: bad arguments"); return ONTOVAE_EINVAL; }
+    if (k1 == k0) return ONTOVAE_OK;
+    hipLaunchKernelGGL(ov_vals_to_dense_kernel, dim3((unsigned)((k1 - k0 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       vals, entry_row, entry_col, k0, k1, dense, ld);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_dense_to_vals(const float* dense, int64_t ld, const int32_t* entry_row, const int32_t* entry_col, int64_t k0,
+                                     int64_t k1, float* vals, void* stream) {
+    if (!vals || !entry_row || !entry_col || !dense || k1 < k0) { ontovae_set_error("dense_to_vals: bad arguments"); return ONTOVAE_EINVAL; }
+    if (k1 == k0) return ONTOVAE_OK;
+    hipLaunchKernelGGL(ov_dense_to_vals_kernel, dim3((unsigned)((k1 - k0 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       dense, ld, entry_row, entry_col, k0, k1, vals);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}

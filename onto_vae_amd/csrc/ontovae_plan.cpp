@@ -1,0 +1,334 @@
+// Host-side mask packer: the reference's list of dense 0/1 ontology masks -> one sparse operator
+// over the node space [panel | genes] in CSR (forward, weight gradient) and CSC (backward) form.
+//
+// Replaces reference onto_vae/modules.py:268-275 (dense repeat_interleave expansion) and makes the
+// gradient mask of onto_vae/vae_model.py:168-169 implicit.  Input contract: reference
+// onto_vae/ontobj.py:386-392 (mask i: rows = level i+1, cols = [level i | ... | level 0]).
+#include "ontovae_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <tuple>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void ontovae_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ontovae_last_error(void) { return g_err; }
+extern "C" int ontovae_abi_version(void) { return ONTOVAE_ABI_VERSION; }
+
+struct ontovae_plan {
+    ontovae_dims_t dims;
+    std::vector<int32_t> n_level;      // terms per level, K entries
+    std::vector<int32_t> cum;          // C_d = nu * sum_{j<=d} n_j, K entries
+    std::vector<int32_t> level_begin;  // K+1 entries (level K = genes)
+    std::vector<int32_t> level_end;
+    std::vector<int32_t> rowptr, colidx, cscptr, csc_row, csc_k;
+    std::vector<int32_t> e_layer, e_row, e_col;   // dense coordinates per packed entry
+    std::vector<int64_t> layer_k0;     // first packed entry of each layer (K+1)
+};
+
+struct Link { int32_t layer, row, col; };
+
+static int build(int32_t K, const int32_t* rows, const int32_t* cols, int32_t nu, std::vector<Link>& links,
+                 ontovae_plan_t** out) {
+    if (K < 1 || nu < 1 || !rows || !cols || !out) {
+        ontovae_set_error("plan: bad arguments (K=%d nu=%d)", K, nu);
+        return ONTOVAE_EINVAL;
+    }
+    ontovae_plan* p = new (std::nothrow) ontovae_plan();
+    if (!p) return ONTOVAE_ENOMEM;
+    // level sizes from the shapes; cols[i] must equal the running sum (ontobj.py:386-392)
+    p->n_level.resize(K);
+    p->n_level[0] = cols[0];
+    int64_t run = cols[0];
+    for (int i = 0; i < K; ++i) {
+        if (rows[i] <= 0 || cols[i] <= 0 || cols[i] != run) {
+            ontovae_set_error("plan: mask %d has shape [%d, %d], expected %lld columns ([level %d | ... | level 0])",
+                              i, rows[i], cols[i], (long long)run, i);
+            delete p;
+            return ONTOVAE_EINVAL;
+        }
+        if (i < K - 1) {
+            p->n_level[i + 1] = rows[i];
+            run += rows[i];
+        }
+    }
+    const int64_t T = run;
+    const int64_t G = rows[K - 1];
+    const int64_t C = T * nu;
+    if (C + G > 0x7fffff00LL) {
+        ontovae_set_error("plan: node space too large");
+        delete p;
+        return ONTOVAE_EINVAL;
+    }
+    p->cum.resize(K);
+    int64_t acc = 0;
+    for (int d = 0; d < K; ++d) {
+        acc += (int64_t)p->n_level[d] * nu;
+        p->cum[d] = (int32_t)acc;
+    }
+    p->level_begin.resize(K + 1);
+    p->level_end.resize(K + 1);
+    for (int d = 0; d < K; ++d) {
+        p->level_begin[d] = (int32_t)(C - p->cum[d]);
+        p->level_end[d] = (int32_t)(d == 0 ? C : C - p->cum[d - 1]);
+    }
+    p->level_begin[K] = (int32_t)C;
+    p->level_end[K] = (int32_t)(C + G);
+
+    // validate + sort + dedupe links
+    for (const Link& l : links) {
+        if (l.layer < 0 || l.layer >= K || l.row < 0 || l.row >= rows[l.layer] || l.col < 0 || l.col >= cols[l.layer]) {
+            ontovae_set_error("plan: link (%d, %d, %d) out of range", l.layer, l.row, l.col);
+            delete p;
+            return ONTOVAE_EINVAL;
+        }
+    }
+    std::sort(links.begin(), links.end(), [](const Link& a, const Link& b) {
+        return std::tie(a.layer, a.row, a.col) < std::tie(b.layer, b.row, b.col);
+    });
+    links.erase(std::unique(links.begin(), links.end(),
+                            [](const Link& a, const Link& b) { return a.layer == b.layer && a.row == b.row && a.col == b.col; }),
+                links.end());
+
+    // expanded nnz per node
+    const int64_t NN = C + G;
+    p->rowptr.assign(NN + 1, 0);
+    int64_t nnz = 0;
+    for (const Link& l : links) {
+        const bool gene = l.layer == K - 1;
+        nnz += gene ? nu : (int64_t)nu * nu;
+    }
+    if (nnz > 0x7fffff00LL) {
+        ontovae_set_error("plan: too many non-zeros");
+        delete p;
+        return ONTOVAE_EINVAL;
+    }
+    p->colidx.resize(nnz);
+    p->e_layer.resize(nnz);
+    p->e_row.resize(nnz);
+    p->e_col.resize(nnz);
+    p->layer_k0.assign(K + 1, 0);
+
+    // Nodes are ordered [level K-1 | ... | level 1 | level 0 | genes]; layer i<K-1 writes level i+1.
+    // Emit rows in node order: layers K-2, K-3, ..., 0, then the gene layer K-1.
+    std::vector<int64_t> lstart(K + 1, 0);   // first link of each layer in the sorted list
+    {
+        size_t j = 0;
+        for (int i = 0; i <= K; ++i) {
+            while (j < links.size() && links[j].layer < i) ++j;
+            lstart[i] = (int64_t)j;
+        }
+    }
+    int64_t k = 0;
+    std::vector<int> order;
+    for (int i = K - 2; i >= 0; --i) order.push_back(i);
+    order.push_back(K - 1);
+    for (int i : order) {
+        const bool gene = i == K - 1;
+        const int32_t in0 = (int32_t)(C - p->cum[i]);                      // node of dense column 0
+        const int32_t out0 = gene ? (int32_t)C : (int32_t)(C - p->cum[i + 1]);
+        const int rep = gene ? 1 : nu;
+        p->layer_k0[i] = k;
+        int64_t j = lstart[i];
+        const int64_t jend = lstart[i + 1];
+        for (int32_t r = 0; r < rows[i]; ++r) {
+            const int64_t j0 = j;
+            while (j < jend && links[j].row == r) ++j;
+            for (int a = 0; a < rep; ++a) {
+                const int32_t node = out0 + r * rep + a;
+                p->rowptr[node] = (int32_t)k;
+                for (int64_t q = j0; q < j; ++q) {
+                    for (int e = 0; e < nu; ++e) {
+                        p->colidx[k] = in0 + links[q].col * nu + e;
+                        p->e_layer[k] = i;
+                        p->e_row[k] = r * rep + a;
+                        p->e_col[k] = links[q].col * nu + e;
+                        ++k;
+                    }
+                }
+            }
+        }
+    }
+    // rowptr currently holds row STARTS for nodes with rows; turn it into a proper monotone pointer
+    // array.  Node order equals emission order except that level 0 (no rows) sits between level 1
+    // and the genes, so a single backward fill is enough.
+    {
+        std::vector<int32_t> start(p->rowptr);
+        std::vector<char> has(NN, 0);
+        for (int d = 1; d <= K; ++d)
+            for (int32_t n = p->level_begin[d]; n < p->level_end[d]; ++n) has[n] = 1;
+        int32_t next = (int32_t)nnz;
+        p->rowptr[NN] = next;
+        for (int64_t n = NN - 1; n >= 0; --n) {
+            if (has[n]) next = start[n];
+            p->rowptr[n] = next;
+        }
+    }
+    p->layer_k0[K] = 0;  // unused sentinel (layers are not contiguous in increasing order)
+
+    // CSC by counting sort over column nodes; rows ascend automatically because k ascends by row
+    p->cscptr.assign(C + 1, 0);
+    for (int64_t q = 0; q < nnz; ++q) p->cscptr[p->colidx[q] + 1]++;
+    for (int64_t c = 0; c < C; ++c) p->cscptr[c + 1] += p->cscptr[c];
+    p->csc_row.resize(nnz);
+    p->csc_k.resize(nnz);
+    {
+        std::vector<int32_t> fill(p->cscptr.begin(), p->cscptr.end() - 1);
+        for (int64_t n = 0; n < NN; ++n)
+            for (int32_t q = p->rowptr[n]; q < p->rowptr[n + 1]; ++q) {
+                const int32_t c = p->colidx[q];
+                const int32_t pos = fill[c]++;
+                p->csc_row[pos] = (int32_t)n;
+                p->csc_k[pos] = q;
+            }
+    }
+    p->dims.G = (int32_t)G;
+    p->dims.T = (int32_t)T;
+    p->dims.K = K;
+    p->dims.nu = nu;
+    p->dims.L = p->cum[0];
+    p->dims.C = (int32_t)C;
+    p->dims.nnz = nnz;
+    p->dims.nnz_links = (int64_t)links.size();
+    *out = p;
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_create(int32_t K, const uint8_t* const* masks, const int32_t* rows, const int32_t* cols,
+                                   int32_t nu, ontovae_plan_t** out) {
+    if (K < 1 || !masks || !rows || !cols) {
+        ontovae_set_error("plan_create: bad arguments");
+        return ONTOVAE_EINVAL;
+    }
+    std::vector<Link> links;
+    for (int i = 0; i < K; ++i) {
+        if (!masks[i] || rows[i] <= 0 || cols[i] <= 0) {
+            ontovae_set_error("plan_create: mask %d is empty", i);
+            return ONTOVAE_EINVAL;
+        }
+        const uint8_t* m = masks[i];
+        for (int32_t r = 0; r < rows[i]; ++r)
+            for (int32_t c = 0; c < cols[i]; ++c) {
+                const uint8_t v = m[(int64_t)r * cols[i] + c];
+                if (v > 1) {
+                    ontovae_set_error("plan_create: mask %d holds a value other than 0/1 at [%d, %d]", i, r, c);
+                    return ONTOVAE_EINVAL;
+                }
+                if (v) links.push_back({i, r, c});
+            }
+    }
+    return build(K, rows, cols, nu, links, out);
+}
+
+extern "C" int ontovae_plan_create_from_links(int32_t K, const int32_t* rows, const int32_t* cols, int32_t nu,
+                                              int64_t n_links, const int32_t* layer, const int32_t* row,
+                                              const int32_t* col, ontovae_plan_t** out) {
+    if (n_links < 0 || (n_links > 0 && (!layer || !row || !col))) {
+        ontovae_set_error("plan_create_from_links: bad arguments");
+        return ONTOVAE_EINVAL;
+    }
+    std::vector<Link> links((size_t)n_links);
+    for (int64_t i = 0; i < n_links; ++i) links[i] = {layer[i], row[i], col[i]};
+    return build(K, rows, cols, nu, links, out);
+}
+
+extern "C" void ontovae_plan_destroy(ontovae_plan_t* plan) { delete plan; }
+
+extern "C" int ontovae_plan_dims(const ontovae_plan_t* plan, ontovae_dims_t* out) {
+    if (!plan || !out) return ONTOVAE_EINVAL;
+    *out = plan->dims;
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_levels(const ontovae_plan_t* plan, int32_t* node_begin, int32_t* node_end) {
+    if (!plan || !node_begin || !node_end) return ONTOVAE_EINVAL;
+    std::memcpy(node_begin, plan->level_begin.data(), sizeof(int32_t) * plan->level_begin.size());
+    std::memcpy(node_end, plan->level_end.data(), sizeof(int32_t) * plan->level_end.size());
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_export(const ontovae_plan_t* plan, int32_t* rowptr, int32_t* colidx, int32_t* cscptr,
+                                   int32_t* csc_row, int32_t* csc_k) {
+    if (!plan) return ONTOVAE_EINVAL;
+    auto cp = [](int32_t* dst, const std::vector<int32_t>& v) {
+        if (dst && !v.empty()) std::memcpy(dst, v.data(), sizeof(int32_t) * v.size());
+    };
+    cp(rowptr, plan->rowptr);
+    cp(colidx, plan->colidx);
+    cp(cscptr, plan->cscptr);
+    cp(csc_row, plan->csc_row);
+    cp(csc_k, plan->csc_k);
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_entry_coords(const ontovae_plan_t* plan, int32_t* layer, int32_t* row, int32_t* col) {
+    if (!plan) return ONTOVAE_EINVAL;
+    const size_t n = plan->e_layer.size();
+    if (layer && n) std::memcpy(layer, plan->e_layer.data(), n * sizeof(int32_t));
+    if (row && n) std::memcpy(row, plan->e_row.data(), n * sizeof(int32_t));
+    if (col && n) std::memcpy(col, plan->e_col.data(), n * sizeof(int32_t));
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_layer_node0(const ontovae_plan_t* plan, int32_t layer, int32_t* node0, int32_t* n_out) {
+    if (!plan || layer < 0 || layer >= plan->dims.K) {
+        ontovae_set_error("layer_node0: bad layer %d", layer);
+        return ONTOVAE_EINVAL;
+    }
+    const int d = layer + 1;  // layer i writes level i+1 (level K = genes)
+    if (node0) *node0 = plan->level_begin[d];
+    if (n_out) *n_out = plan->level_end[d] - plan->level_begin[d];
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_unpack_mask(const ontovae_plan_t* plan, int32_t layer, uint8_t* out, int64_t out_len) {
+    if (!plan || !out || layer < 0 || layer >= plan->dims.K) {
+        ontovae_set_error("unpack_mask: bad arguments");
+        return ONTOVAE_EINVAL;
+    }
+    const int K = plan->dims.K;
+    const int32_t C = plan->dims.C;
+    const int64_t n_in = plan->cum[layer];
+    const int d = layer + 1;
+    const int32_t node0 = plan->level_begin[d];
+    const int64_t n_out = plan->level_end[d] - node0;
+    if (out_len != n_in * n_out) {
+        ontovae_set_error("unpack_mask: layer %d is [%lld, %lld], buffer holds %lld", layer, (long long)n_out,
+                          (long long)n_in, (long long)out_len);
+        return ONTOVAE_EINVAL;
+    }
+    (void)K;
+    std::memset(out, 0, (size_t)out_len);
+    const int32_t in0 = C - plan->cum[layer];
+    for (int64_t r = 0; r < n_out; ++r)
+        for (int32_t q = plan->rowptr[node0 + r]; q < plan->rowptr[node0 + r + 1]; ++q)
+            out[r * n_in + (plan->colidx[q] - in0)] = 1;
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_param_layout(const ontovae_dims_t* d, ontovae_layout_t* out) {
+    if (!d || !out) return ONTOVAE_EINVAL;
+    auto up = [](int64_t v) { return (v + 63) / 64 * 64; };   // 256-B aligned segments
+    int64_t o = 0;
+    out->W0 = o;       o = up(o + (int64_t)d->L * d->G);
+    out->b0 = o;       o = up(o + d->L);
+    out->gamma = o;    o = up(o + d->L);
+    out->beta = o;     o = up(o + d->L);
+    out->Wh = o;       o = up(o + 2LL * d->L * d->L);
+    out->bh = o;       o = up(o + 2LL * d->L);
+    out->dec_vals = o; o = up(o + d->nnz);
+    out->dec_bias = o; o = up(o + (int64_t)d->C + d->G);
+    out->total = o;
+    return ONTOVAE_OK;
+}

@@ -1,0 +1,291 @@
+"""Device state + launch layer between the Python OntoVAE surface and the C ABI.
+
+Owns the flat parameter buffer, the packed decoder structure on the device, the workspace and
+the ontovae_ctx_t that every C entry point takes.  torch is plumbing here: it allocates HBM,
+provides the stream and (for data parallel) the collectives.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .packing import MaskPlan
+
+ADAM_DEFAULTS = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)   # torch.optim.AdamW defaults
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    def __init__(self, plan: MaskPlan, device, drop=0.0, z_drop=0.0):
+        self.plan = plan
+        self.device = torch.device(device)
+        self.drop = float(drop)
+        self.z_drop = float(z_drop)
+        lay = plan.layout
+        self.P = torch.zeros(lay.total, dtype=torch.float32, device=self.device)
+        self.M = None
+        self.V = None
+        self.Gr = None
+        self.rmean = torch.zeros(plan.L, dtype=torch.float32, device=self.device)
+        self.rvar = torch.ones(plan.L, dtype=torch.float32, device=self.device)
+        self.nbt = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._ws = None
+        self.max_batch = 0
+        self._ctx = None
+        self._idx = None
+        self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self.rng_offset = 0
+        self._upload_plan()
+
+    # ------------------------------------------------------------------ views of the flat buffer
+    def view(self, name, buf=None):
+        p, lay = self.plan, self.plan.layout
+        buf = self.P if buf is None else buf
+        L, G = p.L, p.G
+        if name == "W0":
+            return buf[lay.W0:lay.W0 + L * G].view(L, G)
+        if name in ("b0", "gamma", "beta"):
+            o = getattr(lay, name)
+            return buf[o:o + L]
+        if name == "Wmu":
+            return buf[lay.Wh:lay.Wh + L * L].view(L, L)
+        if name == "Wlv":
+            return buf[lay.Wh + L * L:lay.Wh + 2 * L * L].view(L, L)
+        if name == "bmu":
+            return buf[lay.bh:lay.bh + L]
+        if name == "blv":
+            return buf[lay.bh + L:lay.bh + 2 * L]
+        if name == "dec_vals":
+            return buf[lay.dec_vals:lay.dec_vals + p.nnz]
+        if name == "dec_bias":
+            return buf[lay.dec_bias:lay.dec_bias + p.C + p.G]
+        raise KeyError(name)
+
+    def layer_vals(self, i, buf=None):
+        k0, k1 = self.plan.layer_entries[i]
+        return self.view("dec_vals", buf)[k0:k1]
+
+    def layer_bias(self, i, buf=None):
+        n0, no = self.plan.layer_nodes[i]
+        return self.view("dec_bias", buf)[n0:n0 + no]
+
+    def layer_dense(self, i, buf=None):
+        """Dense [out_i, in_i] weight of decoder layer i (the reference's state_dict tensor)."""
+        cout, cin = self.plan.layer_shapes[i]
+        k0, k1 = self.plan.layer_entries[i]
+        dense = torch.zeros(cout, cin, dtype=torch.float32, device=self.device)
+        if k1 > k0:
+            er, ec = self._entry_rc()
+            dense[er[k0:k1].long(), ec[k0:k1].long()] = self.layer_vals(i, buf)
+        return dense
+
+    def set_layer_dense(self, i, dense, buf=None):
+        """Import a dense weight; returns the largest |value| found off the mask (dropped)."""
+        cout, cin = self.plan.layer_shapes[i]
+        dense = torch.as_tensor(dense, dtype=torch.float32, device=self.device)
+        if tuple(dense.shape) != (cout, cin):
+            raise ValueError(f"decoder layer {i}: expected shape {(cout, cin)}, got {tuple(dense.shape)}")
+        k0, k1 = self.plan.layer_entries[i]
+        er, ec = self._entry_rc()
+        r, c = er[k0:k1].long(), ec[k0:k1].long()
+        vals = dense[r, c]
+        self.layer_vals(i, buf).copy_(vals)
+        rest = dense.clone()
+        rest[r, c] = 0
+        return float(rest.abs().max()) if rest.numel() else 0.0
+
+    def _entry_rc(self):
+        if self._idx is None or "er" not in self._idx:
+            self._upload_plan()
+        return self._idx["er"], self._idx["ec"]
+
+    # ------------------------------------------------------------------ device plumbing
+    def _upload_plan(self):
+        p = self.plan
+        dev = self.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self._idx = dict(rowptr=t(p.rowptr), colidx=t(p.colidx), cscptr=t(p.cscptr), csc_row=t(p.csc_row),
+                         csc_k=t(p.csc_k), er=t(p.entry_row), ec=t(p.entry_col))
+        self._ctx = None
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        self.device = device
+        for n in ("P", "M", "V", "Gr", "rmean", "rvar", "nbt"):
+            v = getattr(self, n)
+            if v is not None:
+                setattr(self, n, v.to(device))
+        self._ws = None
+        self.max_batch = 0
+        self._upload_plan()
+        return self
+
+    def ensure_opt_state(self):
+        if self.M is None:
+            self.M = torch.zeros_like(self.P)
+            self.V = torch.zeros_like(self.P)
+            self._ctx = None
+
+    def ensure_grad_buffer(self):
+        if self.Gr is None:
+            self.Gr = torch.zeros_like(self.P)
+            self._ctx = None
+
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise _lib.OntoVAEHipError(
+                "the OntoVAE hot path runs on an MI355X through libontovae_hip.so; there is no CPU path "
+                f"(model is on {self.device})")
+
+    def ctx(self, batch):
+        """The ontovae_ctx_t for a launch with `batch` rows (grows the workspace when needed)."""
+        self._require_gpu()
+        L = _lib.lib()
+        if batch > self.max_batch:
+            mb = max(int(batch), 128)
+            nbytes = L.ontovae_workspace_bytes(C.byref(self.plan.dims), mb)
+            if nbytes <= 0:
+                raise _lib.OntoVAEHipError("workspace sizing failed")
+            self._ws = None
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            self.max_batch = mb
+            self._ctx = None
+        if self._ctx is None:
+            c = _lib.Ctx()
+            c.dims = self.plan.dims
+            c.lay = self.plan.layout
+            c.P, c.M, c.V, c.Gr = _ptr(self.P), _ptr(self.M), _ptr(self.V), _ptr(self.Gr)
+            c.bn_rmean, c.bn_rvar, c.bn_nbt = _ptr(self.rmean), _ptr(self.rvar), _ptr(self.nbt)
+            i = self._idx
+            c.rowptr, c.colidx = _ptr(i["rowptr"]), _ptr(i["colidx"])
+            c.cscptr, c.csc_row, c.csc_k = _ptr(i["cscptr"]), _ptr(i["csc_row"]), _ptr(i["csc_k"])
+            c.level_begin = self.plan.level_begin.ctypes.data_as(_lib.c_i32p)
+            c.level_end = self.plan.level_end.ctypes.data_as(_lib.c_i32p)
+            base = self._ws.data_ptr()
+            aligned = (base + 255) // 256 * 256
+            c.workspace = C.c_void_p(aligned)
+            c.workspace_bytes = self._ws.numel() - (aligned - base)
+            c.max_batch = self.max_batch
+            c.drop, c.z_drop, c.seed = self.drop, self.z_drop, self.seed
+            self._ctx = c
+        return self._ctx
+
+    def invalidate(self):
+        self._ctx = None
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def next_offset(self):
+        self.rng_offset += 1
+        return self.rng_offset
+
+    # ------------------------------------------------------------------ argument checks
+    def _x(self, x, xidx):
+        p = self.plan
+        if xidx is None:
+            if x.dim() != 2 or x.shape[1] != p.G:
+                raise ValueError(f"expected x of shape [B, {p.G}], got {tuple(x.shape)}")
+            x = x.to(device=self.device, dtype=torch.float32).contiguous()
+            return x, None, x.shape[0]
+        if x.dim() != 2 or x.shape[1] != p.G or x.dtype != torch.float32 or not x.is_contiguous() or x.device != self.device:
+            raise ValueError("dataset must be a contiguous float32 [N, G] tensor on the model's device")
+        xidx = xidx.to(device=self.device, dtype=torch.int32).contiguous()
+        return x, xidx, xidx.shape[0]
+
+    def _eps(self, eps, B):
+        if eps is None:
+            return None
+        eps = torch.as_tensor(eps, dtype=torch.float32, device=self.device).contiguous()
+        if tuple(eps.shape) != (B, self.plan.L):
+            raise ValueError(f"eps must have shape {(B, self.plan.L)}, got {tuple(eps.shape)}")
+        return eps
+
+    # ------------------------------------------------------------------ entry points
+    def forward(self, x, xidx=None, eps=None, train=False, want_recon=True):
+        x, xidx, B = self._x(x, xidx)
+        eps = self._eps(eps, B)
+        p = self.plan
+        recon = torch.empty(B, p.G, dtype=torch.float32, device=self.device) if want_recon else None
+        mu = torch.empty(B, p.L, dtype=torch.float32, device=self.device)
+        lv = torch.empty(B, p.L, dtype=torch.float32, device=self.device)
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_forward(C.byref(ctx), _ptr(x), _ptr(xidx), B, _ptr(eps), self.next_offset(),
+                                              1 if train else 0, _ptr(recon), _ptr(mu), _ptr(lv), self.stream()), "forward")
+        return recon, mu, lv
+
+    @staticmethod
+    def adamw_struct(lr, step, betas=ADAM_DEFAULTS["betas"], eps=ADAM_DEFAULTS["eps"], weight_decay=ADAM_DEFAULTS["weight_decay"]):
+        b1, b2 = betas
+        bc1 = 1.0 - b1 ** step
+        bc2 = 1.0 - b2 ** step
+        a = _lib.AdamW()
+        a.decay_mul = 1.0 - lr * weight_decay
+        a.one_m_beta1 = 1.0 - b1
+        a.beta2 = b2
+        a.one_m_beta2 = 1.0 - b2
+        a.step_size = lr / bc1
+        a.bc2_sqrt = math.sqrt(bc2)
+        a.eps = eps
+        return a
+
+    def train_step(self, x, xidx, eps, kl_coeff, adam, loss_out, apply_update=True):
+        x, xidx, B = self._x(x, xidx)
+        eps = self._eps(eps, B)
+        if apply_update:
+            self.ensure_opt_state()
+        else:
+            self.ensure_grad_buffer()
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_train_step(C.byref(ctx), _ptr(x), _ptr(xidx), B, _ptr(eps), self.next_offset(),
+                                                 float(kl_coeff), C.byref(adam) if adam is not None else None,
+                                                 1 if apply_update else 0, _ptr(loss_out), self.stream()), "train_step")
+
+    def train_step_dp(self, phase, x, xidx, B_global, eps, kl_coeff, bn_stats, bn_bwd_stats, loss_out, offset):
+        x, xidx, B = self._x(x, xidx)
+        eps = self._eps(eps, B)
+        self.ensure_grad_buffer()
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_train_step_dp(C.byref(ctx), phase, _ptr(x), _ptr(xidx), B, int(B_global), _ptr(eps),
+                                                    offset, float(kl_coeff), _ptr(bn_stats), _ptr(bn_bwd_stats),
+                                                    _ptr(loss_out), self.stream()), f"train_step_dp phase {phase}")
+
+    def adamw_apply(self, adam):
+        self.ensure_opt_state()
+        self.ensure_grad_buffer()
+        ctx = self.ctx(max(self.max_batch, 1))
+        _lib.check(_lib.lib().ontovae_adamw_apply(C.byref(ctx), C.byref(adam), self.stream()), "adamw_apply")
+
+    def eval_step(self, x, xidx, eps, kl_coeff, loss_out):
+        x, xidx, B = self._x(x, xidx)
+        eps = self._eps(eps, B)
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_eval_step(C.byref(ctx), _ptr(x), _ptr(xidx), B, _ptr(eps), self.next_offset(),
+                                                float(kl_coeff), _ptr(loss_out), self.stream()), "eval_step")
+
+    def pass_data(self, x, xidx, eps1, eps2, act_out=None, rec_out=None):
+        x, xidx, B = self._x(x, xidx)
+        eps1, eps2 = self._eps(eps1, B), self._eps(eps2, B)
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_pass_data(C.byref(ctx), _ptr(x), _ptr(xidx), B, _ptr(eps1), _ptr(eps2),
+                                                self.next_offset(), _ptr(act_out), act_out.stride(0) if act_out is not None else 0,
+                                                _ptr(rec_out), rec_out.stride(0) if rec_out is not None else 0, self.stream()),
+                   "pass_data")
+
+    def decoder_forward(self, z, act_out=None, rec_out=None):
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device).contiguous()
+        if z.dim() != 2 or z.shape[1] != self.plan.L:
+            raise ValueError(f"expected z of shape [B, {self.plan.L}]")
+        B = z.shape[0]
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_decoder_forward(C.byref(ctx), _ptr(z), B, _ptr(act_out),
+                                                      act_out.stride(0) if act_out is not None else 0, _ptr(rec_out),
+                                                      rec_out.stride(0) if rec_out is not None else 0, self.stream()),
+                   "decoder_forward")

@@ -1,0 +1,105 @@
+"""Mask packing: the reference's list of dense 0/1 masks -> one sparse operator (CSR + CSC).
+
+Host-side wrapper over the ontovae_plan_* entry points (onto_vae_amd/csrc/ontovae_plan.cpp).
+Replaces the dense repeat_interleave expansion of reference onto_vae/modules.py:268-275.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _i32p(a):
+    return a.ctypes.data_as(_lib.c_i32p)
+
+
+class MaskPlan:
+    """Packed decoder structure.  All arrays are host numpy int32.
+
+    Node space: [0, C) the activation panel in the reference's final concat order
+    [level K-1 | ... | level 1 | level 0 (z)], then [C, C+G) the genes.
+    """
+
+    def __init__(self, mask_list=None, neuronnum=3, links=None, shapes=None):
+        L = _lib.lib()
+        nu = int(neuronnum)
+        handle = C.c_void_p()
+        if mask_list is not None:
+            ms = []
+            for i, m in enumerate(mask_list):
+                m = np.asarray(m.detach().cpu().numpy() if hasattr(m, "detach") else m)
+                if m.ndim != 2:
+                    raise ValueError(f"mask {i} is not a matrix")
+                if not np.all((m == 0) | (m == 1)):
+                    raise ValueError(f"mask {i} holds values other than 0/1")
+                ms.append(np.ascontiguousarray(m != 0, dtype=np.uint8))
+            K = len(ms)
+            rows = np.array([m.shape[0] for m in ms], dtype=np.int32)
+            cols = np.array([m.shape[1] for m in ms], dtype=np.int32)
+            ptrs = (_lib.c_u8p * K)(*[m.ctypes.data_as(_lib.c_u8p) for m in ms])
+            _lib.check(L.ontovae_plan_create(K, ptrs, _i32p(rows), _i32p(cols), nu, C.byref(handle)), "pack masks")
+        else:
+            layer, row, col = (np.ascontiguousarray(a, dtype=np.int32) for a in links)
+            rows = np.ascontiguousarray([s[0] for s in shapes], dtype=np.int32)
+            cols = np.ascontiguousarray([s[1] for s in shapes], dtype=np.int32)
+            K = len(rows)
+            _lib.check(L.ontovae_plan_create_from_links(K, _i32p(rows), _i32p(cols), nu, len(layer), _i32p(layer),
+                                                        _i32p(row), _i32p(col), C.byref(handle)), "pack links")
+        self._h = handle
+        self._L = L
+        self.dims = _lib.Dims()
+        _lib.check(L.ontovae_plan_dims(handle, C.byref(self.dims)), "plan dims")
+        d = self.dims
+        self.G, self.T, self.K, self.nu, self.L, self.C, self.nnz = d.G, d.T, d.K, d.nu, d.L, d.C, int(d.nnz)
+        self.level_begin = np.zeros(self.K + 1, dtype=np.int32)
+        self.level_end = np.zeros(self.K + 1, dtype=np.int32)
+        _lib.check(L.ontovae_plan_levels(handle, _i32p(self.level_begin), _i32p(self.level_end)), "plan levels")
+        n = max(self.nnz, 1)
+        self.rowptr = np.zeros(self.C + self.G + 1, dtype=np.int32)
+        self.colidx = np.zeros(n, dtype=np.int32)
+        self.cscptr = np.zeros(self.C + 1, dtype=np.int32)
+        self.csc_row = np.zeros(n, dtype=np.int32)
+        self.csc_k = np.zeros(n, dtype=np.int32)
+        _lib.check(L.ontovae_plan_export(handle, _i32p(self.rowptr), _i32p(self.colidx), _i32p(self.cscptr),
+                                         _i32p(self.csc_row), _i32p(self.csc_k)), "plan export")
+        self.entry_layer = np.zeros(n, dtype=np.int32)
+        self.entry_row = np.zeros(n, dtype=np.int32)
+        self.entry_col = np.zeros(n, dtype=np.int32)
+        _lib.check(L.ontovae_plan_entry_coords(handle, _i32p(self.entry_layer), _i32p(self.entry_row),
+                                               _i32p(self.entry_col)), "plan coords")
+        # per-layer slices of the packed value array and of the bias array
+        self.layer_entries = []
+        self.layer_nodes = []
+        for i in range(self.K):
+            ks = np.nonzero(self.entry_layer[:self.nnz] == i)[0]
+            k0, k1 = (int(ks[0]), int(ks[-1]) + 1) if len(ks) else (0, 0)
+            assert k1 - k0 == len(ks), "layer entries must be contiguous"
+            self.layer_entries.append((k0, k1))
+            n0, no = C.c_int32(), C.c_int32()
+            _lib.check(L.ontovae_plan_layer_node0(handle, i, C.byref(n0), C.byref(no)), "layer node0")
+            self.layer_nodes.append((n0.value, no.value))
+        # dense shapes of the reference's Linear layers: (out_i, in_i)  (modules.py:269)
+        self.layer_shapes = []
+        cin = self.L
+        for i in range(self.K):
+            cout = self.layer_nodes[i][1]
+            self.layer_shapes.append((cout, cin))
+            cin += cout if i < self.K - 1 else 0
+        self.layout = _lib.Layout()
+        _lib.check(L.ontovae_param_layout(C.byref(self.dims), C.byref(self.layout)), "param layout")
+
+    def unpack_mask(self, layer):
+        """Expanded dense 0/1 mask of layer i, uint8 [out_i, in_i] (== OntoDecoder.masks[i])."""
+        cout, cin = self.layer_shapes[layer]
+        out = np.zeros((cout, cin), dtype=np.uint8)
+        _lib.check(self._L.ontovae_plan_unpack_mask(self._h, layer, out.ctypes.data_as(_lib.c_u8p), out.size), "unpack mask")
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._L.ontovae_plan_destroy(h)
+            except Exception:
+                pass

@@ -1,0 +1,323 @@
+"""OntoVAE on MI355X: the public class surface of reference onto_vae/vae_model.py:18-457.
+
+Constructor, method names, arguments, return types, printed strings, error messages and the
+state_dict layout follow the reference; the arithmetic runs in libontovae_hip.so.
+Differences that a caller can observe are listed in INTEGRATION.md (no autograd graph on the
+returned tensors; eps and dropout masks come from a Philox stream, not from torch's generator;
+losses are fetched once per epoch instead of once per step).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .engine import Engine, ADAM_DEFAULTS
+from .fast_data_loader import FastTensorDataLoader
+from .modules import Encoder, OntoDecoder
+from .packing import MaskPlan
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(it, **kw):
+        return it
+
+
+class FusedAdamW:
+    """torch.optim.AdamW(model.parameters(), lr) of reference vae_model.py:251, as state for the
+    fused HIP update: flat exp_avg / exp_avg_sq buffers in the engine and a step counter."""
+
+    def __init__(self, model, lr=1e-3, betas=ADAM_DEFAULTS["betas"], eps=ADAM_DEFAULTS["eps"],
+                 weight_decay=ADAM_DEFAULTS["weight_decay"]):
+        self.engine = model._engine
+        self.engine.ensure_opt_state()
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.step_count = 0
+
+    def next_hyper(self):
+        self.step_count += 1
+        g = self.param_groups[0]
+        return Engine.adamw_struct(g["lr"], self.step_count, g["betas"], g["eps"], g["weight_decay"])
+
+    def zero_grad(self, set_to_none=True):
+        pass
+
+    def state_dict(self):
+        e = self.engine
+        return {"state": {"step": self.step_count, "exp_avg": e.M.detach().clone(), "exp_avg_sq": e.V.detach().clone()},
+                "param_groups": [dict(g) for g in self.param_groups], "format": "onto_vae_amd.flat.v1"}
+
+    def load_state_dict(self, sd):
+        e = self.engine
+        e.ensure_opt_state()
+        e.M.copy_(sd["state"]["exp_avg"]); e.V.copy_(sd["state"]["exp_avg_sq"])
+        self.step_count = int(sd["state"]["step"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+
+
+def _as_fused(model, optimizer, lr):
+    if isinstance(optimizer, FusedAdamW):
+        return optimizer
+    if optimizer is None:
+        return FusedAdamW(model, lr=lr)
+    if isinstance(optimizer, torch.optim.AdamW):   # the reference's call shape: adopt its hyper-parameters
+        f = getattr(optimizer, "_ontovae_fused", None)
+        if f is None:
+            g = optimizer.param_groups[0]
+            f = FusedAdamW(model, lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"])
+            optimizer._ontovae_fused = f
+        return f
+    raise TypeError("optimizer must be onto_vae_amd.vae_model.FusedAdamW (or a torch.optim.AdamW whose settings are adopted)")
+
+
+class OntoVAE(nn.Module):
+    """A dense encoder combined with an ontology-structured decoder (reference vae_model.py:18-78).
+
+    Parameters are those of the reference: ontobj (anything exposing .description, .genes,
+    .masks, .data and, for terms=, .annot), dataset, top_thresh, bottom_thresh, neuronnum,
+    drop, z_drop.
+    """
+
+    def __init__(self, ontobj, dataset, top_thresh=1000, bottom_thresh=30, neuronnum=3, drop=0.2, z_drop=0.5):
+        super().__init__()
+        key = str(top_thresh) + '_' + str(bottom_thresh)
+        if key not in ontobj.genes.keys():
+            raise ValueError('Available trimming thresholds are: ' + ', '.join(list(ontobj.genes.keys())))
+        self.ontology = ontobj.description
+        self.top = top_thresh
+        self.bottom = bottom_thresh
+        self.genes = ontobj.genes[key]
+        self.in_features = len(self.genes)
+        masks = ontobj.masks[key]['decoder']
+        self.layer_dims_dec = np.array([masks[0].shape[1]] + [m.shape[0] for m in masks])
+        self.latent_dim = self.layer_dims_dec[0] * neuronnum
+        self.layer_dims_enc = [self.latent_dim]
+        self.neuronnum = neuronnum
+        self.drop = drop
+        self.z_drop = z_drop
+        self.device = 'cuda' if torch.cuda.is_available() else 'cpu'
+        self._mask_src = masks
+
+        plan = MaskPlan(masks, neuronnum)
+        if plan.G != self.in_features:
+            raise ValueError(f"the gene mask has {plan.G} rows but ontobj.genes lists {self.in_features} genes")
+        object.__setattr__(self, "_engine", Engine(plan, self.device, drop, z_drop))
+        self.encoder = Encoder(self.in_features, self.latent_dim, self.layer_dims_enc, self.drop, self.z_drop,
+                               engine=self._engine)
+        self.decoder = OntoDecoder(self.in_features, self.layer_dims_dec, masks, self.latent_dim, self.neuronnum,
+                                   engine=self._engine)
+
+        if dataset not in ontobj.data[key].keys():
+            raise ValueError('Available datasets are: ' + ', '.join(list(ontobj.data[key].keys())))
+        self.X = ontobj.data[key][dataset]
+        # test hook: callable(B) -> eps [B, L]; None = Philox stream inside the kernels
+        self.eps_source = None
+        self.inference_batch = 4096
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def mask_list(self):
+        """vae_model.py:51-52: the masks as float32 tensors (built on access, they are dense)."""
+        return [torch.tensor(np.asarray(m), dtype=torch.float32) for m in self._mask_src]
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self._engine.device))
+        if probe.device != self._engine.device:
+            self._engine.to(probe.device)
+            self.device = str(probe.device.type)
+            self.encoder.rebind()
+            self.decoder.rebind()
+        if probe.dtype != torch.float32:
+            raise TypeError("the HIP OntoVAE computes in float32 only")
+        return self
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._engine.invalidate()
+
+    def _eps(self, B):
+        return None if self.eps_source is None else self.eps_source(B)
+
+    # ------------------------------------------------------------------ reference methods
+    def reparameterize(self, mu, log_var):
+        """vae_model.py:80-93 on caller-supplied tensors (torch ops; the training path fuses this)."""
+        sigma = torch.exp(0.5 * log_var)
+        eps = self._eps(mu.shape[0])
+        eps = torch.randn_like(sigma) if eps is None else torch.as_tensor(eps, dtype=sigma.dtype, device=sigma.device)
+        return mu + eps * sigma
+
+    def get_embedding(self, x):
+        """vae_model.py:95-106."""
+        mu, log_var = self.encoder(x)
+        return self.reparameterize(mu, log_var)
+
+    def forward(self, x):
+        """vae_model.py:108-118.  Returns (reconstruction, mu, log_var), each [B, .] on the device."""
+        x = torch.as_tensor(x)
+        return self._engine.forward(x, eps=self._eps(x.shape[0]), train=self.training)
+
+    def vae_loss(self, reconstruction, mu, log_var, data, kl_coeff, mode='train', run=None):
+        """vae_model.py:120-129 on caller-supplied tensors (torch ops; the training path fuses this)."""
+        kl_loss = -0.5 * torch.sum(1. + log_var - mu.pow(2) - log_var.exp())
+        rec_loss = torch.sum((reconstruction - data) ** 2)
+        if run is not None:
+            run["metrics/" + mode + "/kl_loss"].log(kl_loss)
+            run["metrics/" + mode + "/rec_loss"].log(rec_loss)
+        return torch.mean(rec_loss + kl_coeff * kl_loss)
+
+    def _batches(self, dataloader):
+        """Yield (x, xidx) per batch: zero-copy (dataset, indices) for the HBM-resident loader,
+        (batch, None) for any other iterable of tuples (vae_model.py:153-156)."""
+        if isinstance(dataloader, FastTensorDataLoader) and dataloader.device == self._engine.device \
+                and dataloader.tensors[0].dtype == torch.float32 and dataloader.tensors[0].is_contiguous():
+            iter(dataloader)
+            while True:
+                idx = dataloader.next_indices()
+                if idx is None:
+                    return
+                yield dataloader.tensors[0], idx
+        else:
+            for data in dataloader:
+                yield data[0], None
+
+    def _collect(self, losses, n, mode, run):
+        """One device-to-host copy per round instead of loss.item() per step (vae_model.py:162)."""
+        host = losses[:n].cpu().double().numpy()
+        if run is not None:
+            for rec, kl, _ in host:
+                run["metrics/" + mode + "/kl_loss"].log(kl)
+                run["metrics/" + mode + "/rec_loss"].log(rec)
+        running_loss = 0.0
+        for v in host[:, 2]:
+            running_loss += float(v)
+        return running_loss
+
+    def train_round(self, dataloader, lr, kl_coeff, optimizer, run=None):
+        """vae_model.py:131-180: one epoch of forward, ELBO, backward, masked AdamW, clamp."""
+        self.train()
+        opt = _as_fused(self, optimizer, lr)
+        losses = torch.zeros(max(len(dataloader), 1), 3, dtype=torch.float32, device=self._engine.device)
+        n = 0
+        for x, xidx in tqdm(self._batches(dataloader), total=len(dataloader), disable=None):
+            B = x.shape[0] if xidx is None else xidx.shape[0]
+            if self._dp_world() > 1:
+                from .parallel import dp_train_step
+                dp_train_step(self, x, xidx, self._eps(B), kl_coeff, opt, losses[n])
+            else:
+                self._engine.train_step(x, xidx, self._eps(B), kl_coeff, opt.next_hyper(), losses[n])
+            n += 1
+        return self._collect(losses, n, 'train', run) / len(dataloader)
+
+    def val_round(self, dataloader, kl_coeff, run=None):
+        """vae_model.py:182-213: eval-mode forward + loss (eps is still sampled)."""
+        self.eval()
+        losses = torch.zeros(max(len(dataloader), 1), 3, dtype=torch.float32, device=self._engine.device)
+        n = 0
+        for x, xidx in tqdm(self._batches(dataloader), total=len(dataloader), disable=None):
+            B = x.shape[0] if xidx is None else xidx.shape[0]
+            self._engine.eval_step(x, xidx, self._eps(B), kl_coeff, losses[n])
+            n += 1
+        return self._collect(losses, n, 'val', run) / len(dataloader)
+
+    @staticmethod
+    def _dp_world():
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def train_model(self, modelpath, lr=1e-4, kl_coeff=1e-4, batch_size=128, epochs=300, run=None):
+        """vae_model.py:215-273: 80/20 split (seed 42), AdamW defaults, best-val checkpointing."""
+        indices = np.random.RandomState(seed=42).permutation(self.X.shape[0])
+        X_train_ind = indices[:round(len(indices) * 0.8)]
+        X_val_ind = indices[round(len(indices) * 0.8):]
+        X_train = torch.tensor(self.X[X_train_ind, :], dtype=torch.float32)
+        X_val = torch.tensor(self.X[X_val_ind, :], dtype=torch.float32)
+        dev = self._engine.device
+        trainloader = FastTensorDataLoader(X_train, batch_size=batch_size, shuffle=True, device=dev)
+        valloader = FastTensorDataLoader(X_val, batch_size=batch_size, shuffle=False, device=dev)
+
+        val_loss_min = float('inf')
+        optimizer = FusedAdamW(self, lr=lr)
+
+        for epoch in range(epochs):
+            print(f"Epoch {epoch+1} of {epochs}")
+            train_epoch_loss = self.train_round(trainloader, lr, kl_coeff, optimizer, run)
+            val_epoch_loss = self.val_round(valloader, kl_coeff, run)
+
+            if run is not None:
+                run["metrics/train/loss"].log(train_epoch_loss)
+                run["metrics/val/loss"].log(val_epoch_loss)
+
+            if val_epoch_loss < val_loss_min:
+                print('New best model!')
+                if modelpath is not None and (self._dp_world() == 1 or torch.distributed.get_rank() == 0):
+                    torch.save({
+                        'epoch': epoch,
+                        'model_state_dict': self.state_dict(),
+                        'optimizer_state_dict': optimizer.state_dict(),
+                        'loss': val_epoch_loss,
+                    }, modelpath)
+                val_loss_min = val_epoch_loss
+
+            print(f"Train Loss: {train_epoch_loss:.4f}")
+            print(f"Val Loss: {val_epoch_loss:.4f}")
+
+    def _pass_data(self, data, output):
+        """vae_model.py:276-327, streamed in batches: eval mode, two eps draws per sample, the
+        nu-mean and the [z | activities] concatenation done on the device."""
+        self.eval()
+        e = self._engine
+        data = torch.as_tensor(data, dtype=torch.float32)
+        N = data.shape[0]
+        T, G = e.plan.T, e.plan.G
+        out = torch.empty(N, T if output == 'act' else G, dtype=torch.float32, device=e.device)
+        step = int(self.inference_batch)
+        for i in range(0, N, step):
+            xb = data[i:i + step].to(e.device)
+            B = xb.shape[0]
+            eps1, eps2 = self._eps(B), self._eps(B)
+            if output == 'act':
+                e.pass_data(xb, None, eps1, eps2, act_out=out[i:i + B])
+            else:
+                e.pass_data(xb, None, eps1, eps2, rec_out=out[i:i + B])
+        return out.cpu().numpy()
+
+    # ---- shared pieces of the three retrieval methods --------------------------------------
+    def _key(self):
+        return str(self.top) + '_' + str(self.bottom)
+
+    def _dataset_copy(self, ontobj, dataset):
+        if self.ontology != ontobj.description:
+            raise ValueError('Wrong ontology provided, should be ' + self.ontology)
+        return ontobj.data[self._key()][dataset].copy()
+
+    def _subset_terms(self, ontobj, res, terms):
+        if terms is None:
+            return res
+        annot = ontobj.annot[self._key()]
+        return res[:, annot[annot.ID.isin(terms)].index.to_numpy()]
+
+    def _subset_genes(self, ontobj, res, rec_genes):
+        if rec_genes is None:
+            return res
+        onto_genes = ontobj.genes[self._key()]
+        return res[:, np.array([onto_genes.index(g) for g in rec_genes])]
+
+    def get_pathway_activities(self, ontobj, dataset, terms=None):
+        """vae_model.py:330-361: [N, T] float32 activities, columns ordered by depth."""
+        data = self._dataset_copy(ontobj, dataset)
+        return self._subset_terms(ontobj, self._pass_data(data, 'act'), terms)
+
+    def get_reconstructed_values(self, ontobj, dataset, rec_genes=None):
+        """vae_model.py:364-395: [N, G] float32 reconstruction."""
+        data = self._dataset_copy(ontobj, dataset)
+        return self._subset_genes(ontobj, self._pass_data(data, 'rec'), rec_genes)
+
+    def perturbation(self, ontobj, dataset, genes, values, output='terms', terms=None, rec_genes=None):
+        """vae_model.py:398-456: overwrite the listed gene columns with `values`, then the same
+        pass as above ('terms' -> activities, 'genes' -> reconstruction)."""
+        data = self._dataset_copy(ontobj, dataset)
+        for g, v in zip(genes, values):
+            data[:, self.genes.index(g)] = v
+        if output not in ('terms', 'genes'):
+            raise ValueError("output must be 'terms' or 'genes'")
+        res = self._pass_data(data, 'act' if output == 'terms' else 'rec')
+        return self._subset_genes(ontobj, self._subset_terms(ontobj, res, terms), rec_genes)

@@ -1,0 +1,275 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference's golden fixtures and
+against the CPU oracle on the same seeded inputs.  Tolerances: loss/rec/kl 1e-4 relative
+(north_star), activities/reconstructions per conftest.act_close, parameters 1e-4 rel + 1e-6 abs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import NOISE_KEYS, act_close, sub
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+def make_model(masks, nu, sd=None, X=None, drop=0.0, z_drop=0.0):
+    from onto_vae_amd.synthetic import StubOntobj
+    from onto_vae_amd.vae_model import OntoVAE
+    G = masks[-1].shape[0]
+    onto = StubOntobj(masks, data={"d": X if X is not None else np.zeros((4, G))})
+    model = OntoVAE(onto, "d", neuronnum=nu, drop=drop, z_drop=z_drop)
+    assert model._engine.device.type == "cuda"
+    if sd is not None:
+        model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    return model, onto
+
+
+def feed(model, arrays):
+    q = [torch.as_tensor(a) for a in arrays]
+    model.eps_source = lambda B: q.pop(0)
+    return q
+
+
+def hip_state(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def adam_state(model, which):
+    """exp_avg / exp_avg_sq in the reference's per-parameter (dense) layout."""
+    e = model._engine
+    buf = e.M if which == "m" else e.V
+    out = {"encoder.encoder.0.0.weight": e.view("W0", buf), "encoder.encoder.0.0.bias": e.view("b0", buf),
+           "encoder.encoder.0.1.weight": e.view("gamma", buf), "encoder.encoder.0.1.bias": e.view("beta", buf),
+           "encoder.mu.0.weight": e.view("Wmu", buf), "encoder.mu.0.bias": e.view("bmu", buf),
+           "encoder.logvar.0.weight": e.view("Wlv", buf), "encoder.logvar.0.bias": e.view("blv", buf)}
+    for i in range(e.plan.K):
+        out[f"decoder.decoder.{i}.0.weight"] = e.layer_dense(i, buf)
+        out[f"decoder.decoder.{i}.0.bias"] = e.layer_bias(i, buf)
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+def check_params(got, want, steps_lr, rtol=1e-4, atol=1e-6):
+    for k, v in want.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(v), k
+        elif k in NOISE_KEYS:
+            assert np.abs(got[k] - v).max() <= 2.1 * steps_lr + 1e-6, k
+        else:
+            np.testing.assert_allclose(got[k], v, rtol=rtol, atol=atol, err_msg=k)
+
+
+# ------------------------------------------------------------------------------ golden fixtures
+def test_forward_golden(case):
+    _, fx, masks = case
+    model, _ = make_model(masks, int(fx["nu"]), sub(fx, "sd0/"))
+    model.train()
+    feed(model, [fx["eps/0"]])
+    recon, mu, lv = model.forward(torch.as_tensor(fx["x/0"]))
+    assert act_close(recon.cpu().numpy(), fx["fwd/recon"])
+    assert act_close(mu.cpu().numpy(), fx["fwd/mu"]) and act_close(lv.cpu().numpy(), fx["fwd/log_var"])
+    loss = model.vae_loss(recon, mu, lv, torch.as_tensor(fx["x/0"]).cuda(), float(fx["kl_coeff"]))
+    np.testing.assert_allclose(float(loss), fx["fwd/rec_kl_loss"][2], rtol=REL)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_train_steps_golden(case, fused):
+    from onto_vae_amd.vae_model import FusedAdamW
+    _, fx, masks = case
+    steps, lr, kc = int(fx["steps"]), float(fx["lr"]), float(fx["kl_coeff"])
+    model, _ = make_model(masks, int(fx["nu"]), sub(fx, "sd0/"))
+    opt = FusedAdamW(model, lr=lr)
+    e = model._engine
+    out = torch.zeros(steps, 3, device="cuda")
+    for s in range(steps):
+        x, eps = torch.as_tensor(fx[f"x/{s}"]), torch.as_tensor(fx[f"eps/{s}"])
+        if fused:
+            e.train_step(x, None, eps, kc, opt.next_hyper(), out[s])
+        else:  # gradients to the flat buffer, then the stand-alone AdamW kernel (the data-parallel path)
+            e.train_step(x, None, eps, kc, None, out[s], apply_update=False)
+            e.adamw_apply(opt.next_hyper())
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, 0], fx["train/rec"], rtol=REL)
+    np.testing.assert_allclose(got[:, 1], fx["train/kl"], rtol=REL)
+    np.testing.assert_allclose(got[:, 2], fx["train/loss"], rtol=REL)
+    check_params(hip_state(model), sub(fx, "sdT/"), steps * lr)
+    for which in ("m", "v"):
+        st = adam_state(model, which)
+        for k, v in sub(fx, f"adam_{which}/").items():
+            if k not in NOISE_KEYS:
+                np.testing.assert_allclose(st[k], v, rtol=1e-3, atol=1e-5, err_msg=f"{which} {k}")
+    for i in range(e.plan.K):  # non-negative decoder weights (vae_model.py:175-176)
+        assert float(e.layer_vals(i).min()) >= 0.0
+
+
+def test_train_round_api_golden(case):
+    """Same steps through OntoVAE.train_round with a plain list of batches (the reference's call shape)."""
+    from onto_vae_amd.vae_model import FusedAdamW
+    _, fx, masks = case
+    steps, lr, kc = int(fx["steps"]), float(fx["lr"]), float(fx["kl_coeff"])
+    model, _ = make_model(masks, int(fx["nu"]), sub(fx, "sd0/"))
+    opt = FusedAdamW(model, lr=lr)
+    feed(model, [fx[f"eps/{s}"] for s in range(steps)])
+    batches = [(torch.as_tensor(fx[f"x/{s}"]),) for s in range(steps)]
+    mean_loss = model.train_round(batches, lr, kc, opt)
+    np.testing.assert_allclose(mean_loss, fx["train/loss"].mean(), rtol=REL)
+    assert model.training
+
+
+def test_val_and_inference_golden(case):
+    _, fx, masks = case
+    kc = float(fx["kl_coeff"])
+    model, onto = make_model(masks, int(fx["nu"]), sub(fx, "sdT/"))
+    feed(model, [fx["val/eps"]])
+    vloss = model.val_round([(torch.as_tensor(fx["val/x"]),)], kc)
+    np.testing.assert_allclose(vloss, fx["val/rec_kl_loss"][2], rtol=REL)
+    assert not model.training
+    onto.add_dataset("inf", fx["inf/X"])
+    e1, e2 = fx["inf/eps1"], fx["inf/eps2"]
+    feed(model, [e1, e2])
+    act = model.get_pathway_activities(onto, "inf")
+    assert act.dtype == np.float32 and act_close(act, fx["inf/act"])
+    feed(model, [e1, e2])
+    assert act_close(model.get_reconstructed_values(onto, "inf"), fx["inf/rec"])
+    genes = [onto.genes["1000_30"][int(i)] for i in fx["inf/pert_gene_idx"]]
+    feed(model, [e1, e2])
+    assert act_close(model.perturbation(onto, "inf", genes, list(fx["inf/pert_values"]), output="terms"), fx["inf/pert_act"])
+    feed(model, [e1, e2])
+    assert act_close(model.perturbation(onto, "inf", genes, list(fx["inf/pert_values"]), output="genes"), fx["inf/pert_rec"])
+    # batching the pass must not change anything (BN in eval mode is per row)
+    model.inference_batch = 4
+    chunks = lambda a: [a[i:i + 4] for i in range(0, len(a), 4)]
+    feed(model, [v for pair in zip(chunks(e1), chunks(e2)) for v in pair])
+    assert act_close(model.get_pathway_activities(onto, "inf"), fx["inf/act"])
+    # subsetting by term id and by gene name
+    ids = list(onto.annot["1000_30"].ID[[1, 5]])
+    feed(model, [e1[:4], e2[:4], e1[4:8], e2[4:8], e1[8:], e2[8:]])
+    sub_act = model.get_pathway_activities(onto, "inf", terms=ids)
+    assert sub_act.shape[1] == 2 and act_close(sub_act, fx["inf/act"][:, [1, 5]])
+
+
+# ------------------------------------------------------------------------------ HIP vs oracle
+def medium(seed=11, counts=(20, 30, 40, 25), G=1000, nu=3):
+    from onto_vae_amd.synthetic import synthetic_masks, random_state_dict
+    masks = synthetic_masks(list(counts), G, seed)
+    return masks, random_state_dict(masks, nu, seed + 1)
+
+
+@pytest.mark.parametrize("B", [128, 200, 37, 2])
+def test_train_vs_oracle_batch_sizes(B):
+    """Every batch-size regime of the kernels (1, 2 and 4 columns per lane, ragged tails)."""
+    from ontovae_oracle import OracleOntoVAE
+    from onto_vae_amd.vae_model import FusedAdamW
+    masks, sd = medium()
+    nu, lr, kc = 3, 1e-3, 1e-4
+    rng = np.random.RandomState(B)
+    o = OracleOntoVAE(masks, nu)
+    o.load_state_dict(sd)
+    model, _ = make_model(masks, nu, sd)
+    opt = FusedAdamW(model, lr=lr)
+    out = torch.zeros(3, 3, device="cuda")
+    want = []
+    for s in range(3):
+        x = np.log1p(rng.poisson(0.5, size=(B, 1000))).astype(np.float32)
+        eps = rng.standard_normal((B, 60)).astype(np.float32)
+        want.append(o.train_step(x, eps, lr, kc))
+        model._engine.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), kc, opt.next_hyper(), out[s])
+    np.testing.assert_allclose(out.cpu().numpy(), np.array(want), rtol=REL)
+    check_params(hip_state(model), o.state_dict(), 3 * lr, rtol=2e-4, atol=2e-6)
+
+
+def test_row_gather_equals_plain_batch():
+    """(dataset, row indices) addressing gives the same step as a gathered batch."""
+    from onto_vae_amd.vae_model import FusedAdamW
+    masks, sd = medium()
+    rng = np.random.RandomState(3)
+    X = torch.as_tensor(np.log1p(rng.poisson(0.5, size=(300, 1000))).astype(np.float32)).cuda()
+    idx = torch.as_tensor(rng.permutation(300)[:96].astype(np.int32)).cuda()
+    eps = torch.as_tensor(rng.standard_normal((96, 60)).astype(np.float32))
+    res = []
+    for use_idx in (True, False):
+        model, _ = make_model(masks, 3, sd)
+        opt = FusedAdamW(model, lr=1e-3)
+        out = torch.zeros(3, device="cuda")
+        if use_idx:
+            model._engine.train_step(X, idx, eps, 1e-4, opt.next_hyper(), out)
+        else:
+            model._engine.train_step(X[idx.long()], None, eps, 1e-4, opt.next_hyper(), out)
+        res.append((out.cpu().numpy(), model._engine.P.clone()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+
+
+def test_dp_phases_equal_fused_step():
+    """The three-phase data-parallel entry point, run as two simulated ranks on one GPU with the
+    collectives done by hand, equals the single-device step on the global batch."""
+    from onto_vae_amd.vae_model import FusedAdamW
+    from onto_vae_amd.parallel import combine_bn_stats
+    masks, sd = medium()
+    rng = np.random.RandomState(5)
+    B = 96
+    x = torch.as_tensor(np.log1p(rng.poisson(0.5, size=(B, 1000))).astype(np.float32)).cuda()
+    eps = torch.as_tensor(rng.standard_normal((B, 60)).astype(np.float32)).cuda()
+    kc, lr = 1e-4, 1e-3
+    ref, _ = make_model(masks, 3, sd)
+    ropt = FusedAdamW(ref, lr=lr)
+    rout = torch.zeros(3, device="cuda")
+    ref._engine.train_step(x, None, eps, kc, ropt.next_hyper(), rout)
+
+    ranks = [make_model(masks, 3, sd)[0] for _ in range(2)]
+    parts = [(0, 40), (40, 96)]            # uneven shards on purpose
+    stats = [torch.zeros(2, 60, device="cuda") for _ in ranks]
+    bstats = [torch.zeros(2, 60, device="cuda") for _ in ranks]
+    louts = [torch.zeros(3, device="cuda") for _ in ranks]
+    for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+        m._engine.train_step_dp(0, x[a:b], None, B, eps[a:b], kc, stats[r], bstats[r], louts[r], 1)
+    g = combine_bn_stats(torch.stack(stats), torch.tensor([b - a for a, b in parts], device="cuda", dtype=torch.float32))
+    for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+        stats[r].copy_(g)
+        m._engine.train_step_dp(1, x[a:b], None, B, eps[a:b], kc, stats[r], bstats[r], louts[r], 1)
+    bsum = bstats[0] + bstats[1]
+    for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+        bstats[r].copy_(bsum)
+        m._engine.train_step_dp(2, x[a:b], None, B, eps[a:b], kc, stats[r], bstats[r], louts[r], 1)
+    gsum = ranks[0]._engine.Gr + ranks[1]._engine.Gr
+    lsum = louts[0] + louts[1]
+    np.testing.assert_allclose(lsum[:2].cpu().numpy(), rout[:2].cpu().numpy(), rtol=1e-5)
+    for m in ranks:
+        m._engine.Gr.copy_(gsum)
+        o = FusedAdamW(m, lr=lr)
+        m._engine.adamw_apply(o.next_hyper())
+    a, b = hip_state(ranks[0]), hip_state(ref)
+    check_params(a, b, lr, rtol=1e-4, atol=1e-6)
+    assert torch.equal(ranks[0]._engine.P, ranks[1]._engine.P)
+
+
+def test_gobp_syn_full_size_vs_oracle():
+    """BASELINE.json configs[1] at full size (G=20000, T=3000, K=12, B=128): two training steps
+    against the dense CPU oracle, then the off-mask / non-negativity invariants."""
+    from ontovae_oracle import OracleOntoVAE
+    from onto_vae_amd.synthetic import synthetic_masks, synthetic_expression, random_state_dict
+    from onto_vae_amd.vae_model import FusedAdamW
+    masks, rng = synthetic_masks(return_rng=True)
+    X = synthetic_expression(rng, 256, 20000).astype(np.float32)
+    sd = random_state_dict(masks, 3, 77, dense=False)
+    o = OracleOntoVAE(masks, 3)
+    o.load_state_dict(sd)
+    model, _ = make_model(masks, 3, sd)
+    opt = FusedAdamW(model, lr=1e-4)
+    out = torch.zeros(2, 3, device="cuda")
+    want = []
+    erng = np.random.RandomState(1)
+    for s in range(2):
+        x = X[s * 128:(s + 1) * 128]
+        eps = erng.standard_normal((128, 360)).astype(np.float32)
+        want.append(o.train_step(x, eps, 1e-4, 1e-4))
+        model._engine.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), 1e-4, opt.next_hyper(), out[s])
+    np.testing.assert_allclose(out.cpu().numpy(), np.array(want), rtol=REL)
+    e = model._engine
+    got_vals = e.view("dec_vals").cpu().numpy()
+    k0, k1 = e.plan.layer_entries[11]
+    w = o.p["decoder.decoder.11.0.weight"]
+    want_vals = w[e.plan.entry_row[k0:k1], e.plan.entry_col[k0:k1]]
+    np.testing.assert_allclose(got_vals[k0:k1], want_vals, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(e.view("W0").cpu().numpy(), o.p["encoder.encoder.0.0.weight"], rtol=2e-4, atol=2e-6)
+    assert got_vals.min() >= 0.0

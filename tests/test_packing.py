@@ -1,0 +1,96 @@
+"""Mask packing is bit-exact: unpack(pack(M)) equals the reference's expanded masks
+(onto_vae/modules.py:271-275), and the CSR/CSC forms describe the same operator."""
+import numpy as np
+import pytest
+
+from conftest import load_case
+from onto_vae_amd.packing import MaskPlan
+from onto_vae_amd.synthetic import synthetic_masks
+from ontovae_oracle import expand_masks
+
+
+def check_plan(masks, nu):
+    plan = MaskPlan(masks, nu)
+    exp = expand_masks(masks, nu)
+    assert plan.K == len(masks) and plan.G == masks[-1].shape[0] and plan.T == masks[-1].shape[1]
+    assert plan.L == masks[0].shape[1] * nu and plan.C == plan.T * nu
+    assert plan.nnz == int(sum(m.sum() for m in exp))
+    for i, m in enumerate(exp):
+        assert plan.layer_shapes[i] == m.shape
+        assert np.array_equal(plan.unpack_mask(i), m.astype(np.uint8)), f"layer {i}"
+    # entry coordinates address exactly the ones of the expanded masks, row-major within a layer
+    for i, m in enumerate(exp):
+        k0, k1 = plan.layer_entries[i]
+        r, c = plan.entry_row[k0:k1], plan.entry_col[k0:k1]
+        rr, cc = np.nonzero(m)
+        assert np.array_equal(r, rr) and np.array_equal(c, cc)
+    # CSR node mapping: row node = level block + row, col node = C - in_i + col
+    C = plan.C
+    for i in range(plan.K):
+        k0, k1 = plan.layer_entries[i]
+        n0, nout = plan.layer_nodes[i]
+        cin = plan.layer_shapes[i][1]
+        rows_from_ptr = np.repeat(np.arange(C + plan.G), np.diff(plan.rowptr))[k0:k1]
+        assert np.array_equal(rows_from_ptr, n0 + plan.entry_row[k0:k1])
+        assert np.array_equal(plan.colidx[k0:k1], C - cin + plan.entry_col[k0:k1])
+    # CSC is the transpose: same (row, col, k) triples
+    rows = np.repeat(np.arange(C + plan.G), np.diff(plan.rowptr))
+    csc_cols = np.repeat(np.arange(C), np.diff(plan.cscptr))
+    a = set(zip(rows.tolist(), plan.colidx[:plan.nnz].tolist(), range(plan.nnz)))
+    b = set(zip(plan.csc_row[:plan.nnz].tolist(), csc_cols.tolist(), plan.csc_k[:plan.nnz].tolist()))
+    assert a == b
+    for p in range(C):  # rows ascend inside a column
+        seg = plan.csc_row[plan.cscptr[p]:plan.cscptr[p + 1]]
+        assert np.all(np.diff(seg) > 0)
+    # levels tile the panel in reverse order and then the genes
+    assert plan.level_begin[0] == C - plan.L and plan.level_end[0] == C
+    for d in range(1, plan.K):
+        assert plan.level_end[d] == plan.level_begin[d - 1]
+    assert plan.level_begin[plan.K - 1] == 0 and plan.level_begin[plan.K] == C and plan.level_end[plan.K] == C + plan.G
+    return plan
+
+
+def test_pack_golden_cases(case):
+    _, fx, masks = case
+    check_plan(masks, int(fx["nu"]))
+
+
+def test_pack_gobp_syn_counts():
+    masks = synthetic_masks()
+    plan = MaskPlan(masks, 3)
+    assert (plan.G, plan.T, plan.K, plan.L, plan.C) == (20000, 3000, 12, 360, 9000)
+    assert plan.nnz == 520551 and int(plan.dims.nnz_links) == 4595 + 159732
+    assert [s for s in plan.layer_shapes][:3] == [(180, 360), (450, 540), (990, 990)]
+    assert plan.layer_shapes[-1] == (20000, 9000)
+    # spot-check one inner layer and the gene layer bit for bit
+    exp = expand_masks([masks[3], masks[3]], 3)[0]
+    assert np.array_equal(plan.unpack_mask(3), exp.astype(np.uint8))
+    gene = np.repeat(masks[-1], 3, axis=1).astype(np.uint8)
+    assert np.array_equal(plan.unpack_mask(11), gene)
+
+
+def test_pack_from_links_equals_dense():
+    masks = synthetic_masks(counts=[4, 6, 5, 3], n_genes=40, seed=7)
+    layer, row, col = [], [], []
+    for i, m in enumerate(masks):
+        r, c = np.nonzero(m)
+        layer += [i] * len(r); row += r.tolist(); col += c.tolist()
+    perm = np.random.RandomState(0).permutation(len(layer))  # order must not matter, duplicates collapse
+    layer, row, col = (np.array(a)[perm] for a in (layer, row, col))
+    layer, row, col = (np.concatenate([a, a[:5]]) for a in (layer, row, col))
+    a = MaskPlan(masks, 2)
+    b = MaskPlan(neuronnum=2, links=(layer, row, col), shapes=[m.shape for m in masks])
+    for f in ("rowptr", "colidx", "cscptr", "csc_row", "csc_k", "entry_layer", "entry_row", "entry_col"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_pack_rejects_bad_input():
+    good = synthetic_masks(counts=[3, 4], n_genes=10, seed=1)
+    with pytest.raises(ValueError):
+        MaskPlan([good[0], good[1][:, :-1]], 3)          # column count breaks the layout rule
+    bad = [m.copy() for m in good]
+    bad[0][0, 0] = 2
+    with pytest.raises(ValueError):
+        MaskPlan(bad, 3)
+    with pytest.raises(ValueError):
+        MaskPlan(neuronnum=1, links=([0], [99], [0]), shapes=[m.shape for m in good])
