@@ -16,6 +16,14 @@ from .packing import MaskPlan
 ADAM_DEFAULTS = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)   # torch.optim.AdamW defaults
 
 
+def norm_device(device):
+    """torch.device with an explicit index for GPUs, so that device comparisons are meaningful."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -23,7 +31,7 @@ def _ptr(t):
 class Engine:
     def __init__(self, plan: MaskPlan, device, drop=0.0, z_drop=0.0):
         self.plan = plan
-        self.device = torch.device(device)
+        self.device = norm_device(device)
         self.drop = float(drop)
         self.z_drop = float(z_drop)
         lay = plan.layout
@@ -114,7 +122,7 @@ class Engine:
         self._ctx = None
 
     def to(self, device):
-        device = torch.device(device)
+        device = norm_device(device)
         if device == self.device:
             return self
         self.device = device

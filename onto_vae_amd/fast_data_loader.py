@@ -14,13 +14,15 @@ onto_vae/vae_model.py:156).
 """
 import torch
 
+from .engine import norm_device
+
 
 class FastTensorDataLoader:
     def __init__(self, *tensors, batch_size=32, shuffle=False, device=None):
         assert all(t.shape[0] == tensors[0].shape[0] for t in tensors)
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
-        self.device = torch.device(device)
+        self.device = norm_device(device)
         self.tensors = tuple(t.to(self.device) for t in tensors)
         self.dataset_len = self.tensors[0].shape[0]
         self.batch_size = batch_size

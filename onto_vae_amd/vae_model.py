@@ -120,8 +120,9 @@ class OntoVAE(nn.Module):
         return [torch.tensor(np.asarray(m), dtype=torch.float32) for m in self._mask_src]
 
     def _apply(self, fn, recurse=True):
+        from .engine import norm_device
         probe = fn(torch.empty(0, dtype=torch.float32, device=self._engine.device))
-        if probe.device != self._engine.device:
+        if norm_device(probe.device) != self._engine.device:
             self._engine.to(probe.device)
             self.device = str(probe.device.type)
             self.encoder.rebind()
