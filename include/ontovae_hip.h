@@ -238,6 +238,35 @@ int ontovae_vals_to_dense(const float* vals, const int32_t* entry_row, const int
 int ontovae_dense_to_vals(const float* dense, int64_t ld, const int32_t* entry_row,
                           const int32_t* entry_col, int64_t k0, int64_t k1, float* vals, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-phase timing with HIP events on the launch stream (measurement only; the reference has no
+ * counterpart).  ontovae_profile_begin enables the phases in `phase_mask` (bit = phase id) and
+ * reserves `capacity` event pairs per phase; every later launch of an enabled phase is bracketed
+ * by two events until the capacity is used up.  ontovae_profile_read synchronises on them,
+ * returns the elapsed milliseconds of each recorded launch and resets that phase's count.
+ * Not thread safe; begin/end allocate and free events, so call them outside timed regions.
+ * -------------------------------------------------------------------------------------------*/
+enum {
+    ONTOVAE_PHASE_ENC_GEMM = 0,      /* x W0^T (split-K MFMA)                       */
+    ONTOVAE_PHASE_BN_FWD = 1,        /* split-K combine + BatchNorm + ReLU          */
+    ONTOVAE_PHASE_HEADS = 2,         /* mu / log_var heads                          */
+    ONTOVAE_PHASE_REPARAM = 3,       /* z_drop, reparameterisation, KL              */
+    ONTOVAE_PHASE_DEC_FWD_TERMS = 4, /* term levels of the decoder (K-1 launches)   */
+    ONTOVAE_PHASE_DEC_FWD_GENE = 5,  /* gene layer + ELBO epilogue                  */
+    ONTOVAE_PHASE_DEC_BWD = 6,       /* decoder backward data (K launches)          */
+    ONTOVAE_PHASE_LOSS = 7,          /* loss partial reduction                      */
+    ONTOVAE_PHASE_DEC_WGRAD = 8,     /* decoder weight gradient + AdamW + clamp     */
+    ONTOVAE_PHASE_LATENT_BWD = 9,    /* d mu, d log_var                             */
+    ONTOVAE_PHASE_DA_GEMM = 10,      /* heads backward data                         */
+    ONTOVAE_PHASE_DWH = 11,          /* heads weight gradient + AdamW               */
+    ONTOVAE_PHASE_BN_BWD = 12,       /* BatchNorm backward + AdamW of gamma/beta/b0 */
+    ONTOVAE_PHASE_DW0 = 13,          /* dW0 = dh x (MFMA) + fused AdamW             */
+    ONTOVAE_PHASE_COUNT = 14
+};
+int ontovae_profile_begin(uint32_t phase_mask, int32_t capacity);
+int ontovae_profile_read(int32_t phase, float* ms, int32_t cap, int32_t* n_out);
+int ontovae_profile_end(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,11 @@ if it is missing, loading raises, and every compute entry point of the package f
 import ctypes as C
 import os
 
+# torch first: it carries its own libamdhip64; loading ours after it makes the dynamic linker reuse
+# that runtime (same SONAME) instead of bringing a second HIP runtime into the process, which
+# would see no device for streams and memory that torch created.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libontovae_hip.so")
 ABI_VERSION = 1
@@ -83,6 +88,9 @@ def lib():
         "ontovae_gather_rows": [vp, i64, vp, i32, i32, vp, vp],
         "ontovae_vals_to_dense": [vp, vp, vp, i64, i64, vp, i64, vp],
         "ontovae_dense_to_vals": [vp, i64, vp, vp, i64, i64, vp, vp],
+        "ontovae_profile_begin": [C.c_uint32, i32],
+        "ontovae_profile_read": [i32, c_f32p, i32, c_i32p],
+        "ontovae_profile_end": [],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -101,7 +109,11 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_plan_entry_coords", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
             "ontovae_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
             "ontovae_adamw_apply", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
-            "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals"]
+            "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals",
+            "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end"]
+
+PHASES = ["enc_gemm", "bn_fwd", "heads", "reparam", "dec_fwd_terms", "dec_fwd_gene", "dec_bwd", "loss", "dec_wgrad",
+          "latent_bwd", "da_gemm", "dwh", "bn_bwd", "dw0"]
 
 
 def check(rc, what=""):

@@ -24,6 +24,75 @@
 #define OV_LAUNCH_CHECK() OV_HIP_CHECK(hipGetLastError())
 
 // batch columns per wave pass (64 lanes x VEC) and the padded row length, a multiple of it
+// -------------------------------------------------------------------------------------------------
+// Optional per-phase HIP-event timing (bench.py's roofline leg).  Off by default; when a phase is
+// enabled, its launches are bracketed by two events on the launch stream.
+// -------------------------------------------------------------------------------------------------
+struct OvProfState {
+    uint32_t mask = 0;
+    int cap = 0;
+    int n[ONTOVAE_PHASE_COUNT] = {0};
+    hipEvent_t* ev[ONTOVAE_PHASE_COUNT] = {nullptr};   // 2 * cap events per enabled phase
+};
+static OvProfState g_prof;
+
+struct OvProfScope {
+    int phase; hipStream_t st; bool on;
+    OvProfScope(int ph, hipStream_t s) : phase(ph), st(s), on(false) {
+        if ((g_prof.mask >> ph) & 1u) {
+            if (g_prof.n[ph] < g_prof.cap) {
+                on = true;
+                (void)hipEventRecord(g_prof.ev[ph][2 * g_prof.n[ph]], st);
+            }
+        }
+    }
+    ~OvProfScope() {
+        if (on) {
+            (void)hipEventRecord(g_prof.ev[phase][2 * g_prof.n[phase] + 1], st);
+            g_prof.n[phase]++;
+        }
+    }
+};
+
+extern "C" int ontovae_profile_end(void) {
+    for (int ph = 0; ph < ONTOVAE_PHASE_COUNT; ++ph) {
+        if (g_prof.ev[ph]) {
+            for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[ph][i]);
+            delete[] g_prof.ev[ph];
+            g_prof.ev[ph] = nullptr;
+        }
+        g_prof.n[ph] = 0;
+    }
+    g_prof.mask = 0;
+    g_prof.cap = 0;
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_profile_begin(uint32_t phase_mask, int32_t capacity) {
+    ontovae_profile_end();
+    if (capacity < 1 || capacity > (1 << 20)) { ontovae_set_error("profile_begin: bad capacity %d", capacity); return ONTOVAE_EINVAL; }
+    g_prof.cap = capacity;
+    for (int ph = 0; ph < ONTOVAE_PHASE_COUNT; ++ph) {
+        if (!((phase_mask >> ph) & 1u)) continue;
+        g_prof.ev[ph] = new hipEvent_t[2 * capacity];
+        for (int i = 0; i < 2 * capacity; ++i) OV_HIP_CHECK(hipEventCreate(&g_prof.ev[ph][i]));
+    }
+    g_prof.mask = phase_mask;
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_profile_read(int32_t phase, float* ms, int32_t cap, int32_t* n_out) {
+    if (phase < 0 || phase >= ONTOVAE_PHASE_COUNT || !ms || !n_out) { ontovae_set_error("profile_read: bad arguments"); return ONTOVAE_EINVAL; }
+    const int n = std::min(g_prof.n[phase], (int)cap);
+    for (int i = 0; i < n; ++i) {
+        OV_HIP_CHECK(hipEventSynchronize(g_prof.ev[phase][2 * i + 1]));
+        OV_HIP_CHECK(hipEventElapsedTime(&ms[i], g_prof.ev[phase][2 * i], g_prof.ev[phase][2 * i + 1]));
+    }
+    *n_out = n;
+    g_prof.n[phase] = 0;
+    return ONTOVAE_OK;
+}
+
 static inline int ov_vec(int B) { return B <= 64 ? 1 : (B <= 128 ? 2 : 4); }
 static inline int ov_ldb(int B) { const int q = 64 * ov_vec(B); return (B + q - 1) / q * q; }
 
@@ -744,12 +813,14 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     g.C = s.ws.slab; g.ldc = s.ldb; g.slab_stride = (int64_t)d.L * s.ldb; g.kchunk = kchunk;
     const bool vec = (d.G % 4 == 0) && (s.xld % 4 == 0) && ov_al16(g.A) && ov_al16(g.B);
     *S_out = Seff;
+    OvProfScope prof(ONTOVAE_PHASE_ENC_GEMM, s.st);
     return ov_launch_gemm<1, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
 }
 
 static int ov_bn_fwd(OvStep& s, int S, int mode, int Bglobal, float* stats, uint64_t rng_off) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
+    OvProfScope prof(ONTOVAE_PHASE_BN_FWD, s.st);
     hipLaunchKernelGGL(ov_bn_fwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb,
                        c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, c->bn_nbt,
                        s.ws.xhat, s.ws.a, s.ws.bn_mean, s.ws.bn_invstd, stats, d.L, s.B, Bglobal, s.ldb, mode, c->drop, c->seed,
@@ -769,6 +840,7 @@ static int ov_heads_fwd(OvStep& s) {
     g.C = s.ws.mulv; g.ldc = s.ldb; g.kchunk = (d.L + 7) / 8 * 8;
     g.bias = c->P + c->lay.bh;
     const bool vec = (d.L % 4 == 0) && ov_al16(g.A);
+    OvProfScope prof(ONTOVAE_PHASE_HEADS, s.st);
     return ov_launch_gemm<1, 1, true, false, OV_EPI_BIAS>(g, 1, vec, s.st);
 }
 
@@ -778,6 +850,7 @@ static int ov_reparam(OvStep& s, const float* eps, int train, uint64_t rng_off, 
     const int64_t n = (int64_t)d.L * s.ldb;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
     float* zrows = s.ws.act + (int64_t)(d.C - d.L) * s.ldb;
+    OvProfScope prof(ONTOVAE_PHASE_REPARAM, s.st);
     hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks), dim3(256), 0, s.st, s.ws.mulv, eps, s.ws.epsw, zrows, s.ws.kl_part, d.L,
                        s.B, s.ldb, train, c->z_drop, c->seed, rng_off, eps_stream, write_kl);
     OV_LAUNCH_CHECK();
@@ -793,6 +866,7 @@ static int ov_dec_fwd_level(OvStep& s, int nb, int ne, float* rec_out, int64_t r
     dim3 grid((ne - nb + 3) / 4, s.nchunk);
     const float* vals = c->P + c->lay.dec_vals;
     const float* bias = c->P + c->lay.dec_bias;
+    OvProfScope prof(GENE ? ONTOVAE_PHASE_DEC_FWD_GENE : ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
 #define OV_DF(V)                                                                                                        \
     hipLaunchKernelGGL((ov_dec_fwd_kernel<V, GENE>), grid, dim3(256), 0, s.st, c->rowptr, c->colidx, vals, bias, s.ws.act, \
                        nb, ne, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C)
@@ -816,6 +890,7 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne) {
     if (ne <= nb) return ONTOVAE_OK;
     dim3 grid((ne - nb + 3) / 4, s.nchunk);
     const float* vals = c->P + c->lay.dec_vals;
+    OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
 #define OV_DB(V) hipLaunchKernelGGL((ov_dec_bwd_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_row, c->csc_k, vals, s.ws.d, nb, ne, s.ldb)
     if (s.vec == 1) OV_DB(1); else if (s.vec == 2) OV_DB(2); else OV_DB(4);
 #undef OV_DB
@@ -824,6 +899,7 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne) {
 }
 
 static int ov_loss_finalize(OvStep& s, int nrec, int nkl, float kc, float* loss_out) {
+    OvProfScope prof(ONTOVAE_PHASE_LOSS, s.st);
     hipLaunchKernelGGL(ov_loss_finalize_kernel, dim3(1), dim3(1024), 0, s.st, s.ws.rec_part, nrec, s.ws.kl_part, nkl, kc, loss_out);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
@@ -975,6 +1051,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         const int n_term_rows = d.C - d.L;
         const int nrows = n_term_rows + d.G;
         float* G_ = c->Gr;
+        OvProfScope prof(ONTOVAE_PHASE_DEC_WGRAD, s.st);
         hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s.st, c->rowptr, c->colidx, s.ws.act, s.ws.d,
                            c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                            G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
@@ -986,6 +1063,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     {
         const int64_t n = (int64_t)d.L * s.ldb;
         const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
+        OvProfScope prof(ONTOVAE_PHASE_LATENT_BWD, s.st);
         hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(blocks), dim3(256), 0, s.st, s.ws.d + (int64_t)(d.C - d.L) * s.ldb, s.ws.mulv,
                            s.ws.epsw, s.ws.dmulv, d.L, s.B, s.ldb, kc, c->z_drop, c->seed, rng_off);
         OV_LAUNCH_CHECK();
@@ -997,6 +1075,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         g.A = c->P + lay.Wh; g.lda = d.L;          // A(m=l, k=j) = Wh[j*L + l]
         g.B = s.ws.dmulv; g.ldb = s.ldb;
         g.C = s.ws.da; g.ldc = s.ldb; g.kchunk = (2 * d.L + 7) / 8 * 8;
+        OvProfScope prof(ONTOVAE_PHASE_DA_GEMM, s.st);
         if ((rc = ov_launch_gemm<1, 1, false, false, OV_EPI_STORE>(g, 1, false, s.st))) return rc;
     }
     // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv)
@@ -1007,6 +1086,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         g.B = s.ws.a; g.ldb = s.ldb;
         g.ldc = d.L; g.kchunk = (s.B + 7) / 8 * 8;
         g.adam = adam;
+        OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
         if (apply) {
             g.C = c->P + lay.Wh; g.Pm = c->M + lay.Wh; g.Pv = c->V + lay.Wh;
             if ((rc = ov_launch_gemm<1, 1, true, true, OV_EPI_ADAMW>(g, 1, true, s.st))) return rc;
@@ -1022,6 +1102,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     // BN backward
     {
         float* Gr = c->Gr;
+        OvProfScope prof(ONTOVAE_PHASE_BN_BWD, s.st);
         hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd,
                            c->P + lay.gamma, c->P + lay.beta, c->P + lay.b0, c->M ? c->M + lay.gamma : nullptr,
                            c->M ? c->M + lay.beta : nullptr, c->M ? c->M + lay.b0 : nullptr, c->V ? c->V + lay.gamma : nullptr,
@@ -1043,6 +1124,7 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     g.B = s.x; g.ldb = s.xld; g.bgather = s.xidx;     // B(k=b, n=g) = X[row(b) * G + g]
     g.ldc = d.G; g.kchunk = (s.B + 7) / 8 * 8;
     g.adam = ov_adam_from(opt);
+    OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
     if (apply) {
         g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
         return ov_launch_gemm<1, 1, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
