@@ -85,6 +85,9 @@ int ontovae_plan_levels(const ontovae_plan_t* plan, int32_t* node_begin, int32_t
 /* Copy the packed arrays out (host buffers sized from ontovae_plan_dims). */
 int ontovae_plan_export(const ontovae_plan_t* plan, int32_t* rowptr, int32_t* colidx,
                         int32_t* cscptr, int32_t* csc_row, int32_t* csc_k);
+/* csc_split[p], p in [0, C): index of the first gene entry of CSC column p; the entries before it
+ * are the term-to-term links of that column (rows ascend and term nodes precede gene nodes). */
+int ontovae_plan_csc_split(const ontovae_plan_t* plan, int32_t* csc_split);
 /* Dense coordinates of every packed entry, in vals order: entry k is
  * decoder.decoder[layer[k]][0].weight[row[k], col[k]] of the reference's state_dict. */
 int ontovae_plan_entry_coords(const ontovae_plan_t* plan, int32_t* layer, int32_t* row, int32_t* col);
@@ -100,6 +103,35 @@ int ontovae_plan_unpack_mask(const ontovae_plan_t* plan, int32_t layer, uint8_t*
  * few large buffers); `M`, `V` (AdamW moments) and `Gr` (gradients, only used when
  * grads_to_buffer != 0) have the same layout.  Offsets in floats:
  * -------------------------------------------------------------------------------------------*/
+/* Level-scheduled SELL-64 form of the TERM layers (the K-1 small, strictly sequential layers), one
+ * per direction: dir 0 = forward (CSR rows of levels 1..K-1), dir 1 = backward (term part of the CSC
+ * columns of levels K-1..0).  Inside a level the nodes are sorted by list length and cut into slices
+ * of 64 lanes; a node of up to 8 entries owns one lane, longer nodes own 2, 4, .. 64 adjacent lanes
+ * (their partial sums are combined with DPP), and a lane holds its entries in 64x8 chunks
+ * ([8][64] index / weight-position arrays, so every load of a slice is one contiguous 256-B row per
+ * entry slot).  info[lane] = entries of the lane | log2(lanes per node) << 16 | writer lane << 24.
+ * The library keeps a weight copy in this order (`w`, refreshed from P at the start of every pass). */
+typedef struct ontovae_sell {
+    int32_t n_levels;
+    int32_t n_slices;
+    int32_t n_chunks;
+    int32_t all_single_chunk;     /* every slice has exactly one chunk: chunk id == slice id */
+    const int32_t* level_first;   /* host [n_levels]: first slice of each level, in processing order */
+    const int32_t* level_count;   /* host [n_levels] */
+    const int32_t* node;          /* device [n_slices * 64], -1 = unused lane */
+    const int32_t* info;          /* device [n_slices * 64] */
+    const int32_t* chunk0;        /* device [n_slices + 1] */
+    const int32_t* idx;           /* device [n_chunks * 512] gather node of each entry */
+    const int32_t* k;             /* device [n_chunks * 512] position in dec_vals, -1 = padding */
+    float* w;                     /* device scratch [n_chunks * 512] */
+    float* bias;                  /* device scratch [n_slices * 64] (forward only) */
+} ontovae_sell_t;
+
+int ontovae_plan_sell_sizes(const ontovae_plan_t* plan, int32_t dir, int32_t* n_levels, int32_t* n_slices,
+                            int32_t* n_chunks, int32_t* all_single_chunk);
+int ontovae_plan_sell_export(const ontovae_plan_t* plan, int32_t dir, int32_t* level_first, int32_t* level_count,
+                             int32_t* node, int32_t* info, int32_t* chunk0, int32_t* idx, int32_t* k);
+
 typedef struct ontovae_layout {
     int64_t W0;      /* [L, G]   encoder.encoder.0.0.weight                                   */
     int64_t b0;      /* [L]      encoder.encoder.0.0.bias                                     */
@@ -131,6 +163,7 @@ typedef struct ontovae_ctx {
     const int32_t* cscptr;
     const int32_t* csc_row;
     const int32_t* csc_k;
+    const int32_t* csc_split;  /* [C] first GENE entry of each CSC column (term rows sort first) */
     /* level schedule (host arrays, K+1 entries each) */
     const int32_t* level_begin;
     const int32_t* level_end;
@@ -142,7 +175,13 @@ typedef struct ontovae_ctx {
     float drop;                /* Encoder dropout p            (modules.py:48) */
     float z_drop;              /* latent dropout p             (modules.py:58, 63) */
     uint64_t seed;             /* Philox key for dropout masks and internally drawn eps */
+    uint32_t flags;            /* ONTOVAE_FLAG_*: force the general-purpose kernel variants (tests) */
+    ontovae_sell_t sell_fwd;   /* n_slices == 0: not provided, the per-level kernels run instead */
+    ontovae_sell_t sell_bwd;
 } ontovae_ctx_t;
+
+#define ONTOVAE_FLAG_LEVEL_LAUNCHES 1u  /* one launch per decoder level instead of the LDS-fused chain */
+#define ONTOVAE_FLAG_ROW_GENE_LAYER 2u  /* row-per-wave gene layer instead of the LDS-tiled one */
 
 int64_t ontovae_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch);
 

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libontovae_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -30,15 +30,23 @@ class Layout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("W0", "b0", "gamma", "beta", "Wh", "bh", "dec_vals", "dec_bias", "total")]
 
 
+class Sell(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("n_slices", C.c_int32), ("n_chunks", C.c_int32), ("all_single_chunk", C.c_int32),
+                ("level_first", c_i32p), ("level_count", c_i32p),
+                ("node", C.c_void_p), ("info", C.c_void_p), ("chunk0", C.c_void_p), ("idx", C.c_void_p), ("k", C.c_void_p),
+                ("w", C.c_void_p), ("bias", C.c_void_p)]
+
+
 class Ctx(C.Structure):
     _fields_ = [("dims", Dims), ("lay", Layout),
                 ("P", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p), ("Gr", C.c_void_p),
                 ("bn_rmean", C.c_void_p), ("bn_rvar", C.c_void_p), ("bn_nbt", C.c_void_p),
                 ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("cscptr", C.c_void_p), ("csc_row", C.c_void_p),
-                ("csc_k", C.c_void_p),
+                ("csc_k", C.c_void_p), ("csc_split", C.c_void_p),
                 ("level_begin", c_i32p), ("level_end", c_i32p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_batch", C.c_int32),
-                ("drop", C.c_float), ("z_drop", C.c_float), ("seed", C.c_uint64)]
+                ("drop", C.c_float), ("z_drop", C.c_float), ("seed", C.c_uint64), ("flags", C.c_uint32),
+                ("sell_fwd", Sell), ("sell_bwd", Sell)]
 
 
 class AdamW(C.Structure):
@@ -74,6 +82,9 @@ def lib():
         "ontovae_plan_levels": [vp, c_i32p, c_i32p],
         "ontovae_plan_export": [vp, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "ontovae_plan_entry_coords": [vp, c_i32p, c_i32p, c_i32p],
+        "ontovae_plan_csc_split": [vp, c_i32p],
+        "ontovae_plan_sell_sizes": [vp, i32, c_i32p, c_i32p, c_i32p, c_i32p],
+        "ontovae_plan_sell_export": [vp, i32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "ontovae_plan_layer_node0": [vp, i32, c_i32p, c_i32p],
         "ontovae_plan_unpack_mask": [vp, i32, c_u8p, i64],
         "ontovae_param_layout": [C.POINTER(Dims), C.POINTER(Layout)],
@@ -106,7 +117,7 @@ def lib():
 
 EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", "ontovae_plan_create_from_links",
             "ontovae_plan_destroy", "ontovae_plan_dims", "ontovae_plan_levels", "ontovae_plan_export",
-            "ontovae_plan_entry_coords", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
+            "ontovae_plan_entry_coords", "ontovae_plan_csc_split", "ontovae_plan_sell_sizes", "ontovae_plan_sell_export", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
             "ontovae_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
             "ontovae_adamw_apply", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
             "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals",

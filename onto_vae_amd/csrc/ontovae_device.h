@@ -15,10 +15,21 @@ __device__ __forceinline__ int ov_lane() { return threadIdx.x & 63; }
 // through the scalar path
 __device__ __forceinline__ int ov_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// Wave-wide sum on the DPP path (VALU cross-lane moves, no LDS traffic): quads, half rows, rows of
+// 16, then row_bcast15 / row_bcast31 carry the row totals upwards; lane 63 holds the total, which
+// v_readlane broadcasts.  Every lane of the wave must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ov_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float ov_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += ov_dpp<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v += ov_dpp<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v += ov_dpp<0x141, 0xF>(v);   // row_half_mirror
+    v += ov_dpp<0x140, 0xF>(v);   // row_mirror: every lane holds the sum of its row of 16
+    v += ov_dpp<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+    v += ov_dpp<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ double ov_wave_sum_d(double v) {

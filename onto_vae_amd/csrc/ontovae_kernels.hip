@@ -499,6 +499,291 @@ __global__ __launch_bounds__(256) void ov_dec_fwd_kernel(const int32_t* __restri
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Fused term levels.  The K-1 term layers are tiny (41 k non-zeros at GO-BP scale) and strictly
+// sequential, so as separate launches they are pure launch + latency cost.  One workgroup takes BT
+// batch columns, keeps the whole activation panel of those columns in LDS ([C][BT] floats, 144 KB
+// at C = 9000, BT = 4) and walks the levels with a workgroup barrier in between; every level's
+// rows are spread over the 1024 threads.  Results also go to the feature-major panel in HBM for
+// the gene layer and the weight gradient.
+// -------------------------------------------------------------------------------------------------
+#define OV_MAX_LEVELS 64
+struct OvLevels {
+    int n;
+    int first[OV_MAX_LEVELS];   // first slice of each level, in processing order
+    int count[OV_MAX_LEVELS];
+};
+
+// sum over aligned groups of 2^LG lanes; the LAST lane of every group ends up with the group total
+template <int LG>
+__device__ __forceinline__ float ov_group_sum(float v) {
+    if (LG >= 1) v += ov_dpp<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    if (LG >= 2) v += ov_dpp<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    if (LG >= 3) v += ov_dpp<0x141, 0xF>(v);    // row_half_mirror
+    if (LG >= 4) v += ov_dpp<0x140, 0xF>(v);    // row_mirror
+    if (LG >= 5) v += ov_dpp<0x142, 0xA>(v);    // row_bcast15: rows 1, 3 hold 32-lane sums
+    if (LG >= 6) v += ov_dpp<0x143, 0xC>(v);    // row_bcast31: row 3 holds the wave sum
+    return v;
+}
+
+template <int BT>
+__device__ __forceinline__ void ov_group_sum_rt(float (&acc)[BT], int lg) {
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+        float v = acc[j];
+        switch (lg) {                      // wave-uniform
+            case 0: break;
+            case 1: v = ov_group_sum<1>(v); break;
+            case 2: v = ov_group_sum<2>(v); break;
+            case 3: v = ov_group_sum<3>(v); break;
+            case 4: v = ov_group_sum<4>(v); break;
+            case 5: v = ov_group_sum<5>(v); break;
+            default: v = ov_group_sum<6>(v); break;
+        }
+        acc[j] = v;
+    }
+}
+
+// Refresh of the SELL-ordered weight copies from the parameter buffer (start of every pass).
+__global__ __launch_bounds__(256) void ov_sell_refresh_kernel(const float* __restrict__ vals, const float* __restrict__ bias,
+                                                             const int32_t* __restrict__ kf, float* __restrict__ wf, int nf,
+                                                             const int32_t* __restrict__ nodef, float* __restrict__ biasf, int nbf,
+                                                             const int32_t* __restrict__ kb, float* __restrict__ wb, int nb) {
+    const int stride = gridDim.x * 256;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf; i += stride) { const int k = kf[i]; wf[i] = k >= 0 ? vals[k] : 0.f; }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nbf; i += stride) { const int n = nodef[i]; biasf[i] = n >= 0 ? bias[n] : 0.f; }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) { const int k = kb[i]; wb[i] = k >= 0 ? vals[k] : 0.f; }
+}
+
+// -------------------------------------------------------------------------------------------------
+// The term-level chain, forward or backward, as ONE kernel.
+//
+// The K-1 term layers are tiny (41 k non-zeros at GO-BP scale) and strictly sequential, so as
+// separate launches they are pure launch + latency cost.  One workgroup of 16 waves takes BT batch
+// columns and keeps the whole activation panel of those columns in LDS ([C][BT] fp32: 144 KB at
+// C = 9000, BT = 4).  Levels are walked with a workgroup barrier in between; inside a level every
+// wave takes slices of the level-scheduled SELL-64 structure (ontovae_sell_t): per slice ONE round of
+// contiguous loads (lane meta, 8 gather indices, 8 weights), 8 LDS gathers, a DPP sum across the
+// lanes that share a node, one store to LDS and one to the feature-major matrix in HBM.
+//   FWD: out = bias + sum w * panel[idx]      BWD: out = D (gene part, from HBM) + sum w * dpanel[idx]
+// -------------------------------------------------------------------------------------------------
+template <int BT, bool BWD>
+__global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __restrict__ snode, const int32_t* __restrict__ sinfo,
+                                                          const int32_t* __restrict__ chunk0, const int32_t* __restrict__ sidx,
+                                                          const float* __restrict__ sw, const float* __restrict__ sbias,
+                                                          float* __restrict__ glob, int ldb, int z0, int z1, int single,
+                                                          const OvLevels lv) {
+    extern __shared__ __attribute__((aligned(16))) float ov_panel[];
+    const int b0 = blockIdx.x * BT;
+    const int lane = ov_lane();
+    const int wave = ov_wave_id();
+    if (!BWD) {   // level 0 (z) comes from HBM
+        for (int p = z0 + threadIdx.x; p < z1; p += blockDim.x) {
+            float v[BT];
+            ov_ldv<BT>(glob + (int64_t)p * ldb + b0, v);
+            ov_stv<BT>(ov_panel + (int64_t)p * BT, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int li = 0; li < lv.n; ++li) {
+        const int s_end = lv.first[li] + lv.count[li];
+        for (int sl = lv.first[li] + wave; sl < s_end; sl += 16) {
+            const int c0 = single ? sl : chunk0[sl];
+            const int R = single ? 1 : chunk0[sl + 1] - c0;
+            const int node = snode[sl * 64 + lane];
+            const int info = sinfo[sl * 64 + lane];
+            const int cnt = info & 0xFFFF;
+            const int lg = __builtin_amdgcn_readfirstlane((info >> 16) & 7);
+            const bool writer = (info >> 24) & 1;
+            float init[BT];
+#pragma unroll
+            for (int j = 0; j < BT; ++j) init[j] = 0.f;
+            if (writer) {
+                if (BWD) {
+                    ov_ldv<BT>(glob + (int64_t)node * ldb + b0, init);
+                } else {
+                    const float bv = sbias[sl * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < BT; ++j) init[j] = bv;
+                }
+            }
+            float acc[BT];
+#pragma unroll
+            for (int j = 0; j < BT; ++j) acc[j] = 0.f;
+            for (int r = 0; r < R; ++r) {
+                const int base = (c0 + r) * 512 + lane;
+                int id[8];
+                float w[8], v[8][BT];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    id[e] = sidx[base + e * 64];
+                    w[e] = sw[base + e * 64];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov_ldv<BT>(ov_panel + (int64_t)id[e] * BT, v[e]);
+                const int rem = cnt - r * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int j = 0; j < BT; ++j) acc[j] += e < rem ? w[e] * v[e][j] : 0.f;   // padding never enters the sum
+            }
+            ov_group_sum_rt<BT>(acc, lg);
+            if (writer) {
+#pragma unroll
+                for (int j = 0; j < BT; ++j) acc[j] += init[j];
+                ov_stv<BT>(ov_panel + (int64_t)node * BT, acc);
+                ov_stv<BT>(glob + (int64_t)node * ldb + b0, acc);
+            }
+        }
+        // LDS writes must land before the next level reads them; the HBM stores need no wait here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// Cooperative entry prefetch for the row-per-wave gather kernels: the 64 lanes load up to 64
+// (index, weight) pairs of the row in one coalesced pass; v_readlane then hands them out as scalars,
+// so the row gathers that follow have no address dependency left and go out back to back.
+#define OV_RL_I(v, l) __builtin_amdgcn_readlane((v), (l))
+#define OV_RL_F(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (l)))
+
+// acc[VEC] += sum over entries [k0, k1) of w * src[row(entry) * ldb + boff ..]
+template <int VEC, bool INDIRECT>
+__device__ __forceinline__ void ov_gather_rows_acc(float (&acc)[VEC], int k0, int k1, const int32_t* __restrict__ rowidx,
+                                                   const int32_t* __restrict__ kidx, const float* __restrict__ vals,
+                                                   const float* __restrict__ src, int ldb, int boff, int lane) {
+    for (int base = k0; base < k1; base += 64) {
+        const int cnt = min(64, k1 - base);
+        // lanes >= cnt repeat the last entry's row with weight 0: padding that only touches a row the
+        // list really names (never memory that another wave may be writing)
+        const int my_r = rowidx[base + min(lane, cnt - 1)];
+        float my_w = 0.f;
+        if (lane < cnt) my_w = INDIRECT ? vals[kidx[base + lane]] : vals[base + lane];
+        for (int u = 0; u < cnt; u += 8) {
+            float v[8][VEC], w[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int r = OV_RL_I(my_r, u + t);
+                w[t] = OV_RL_F(my_w, u + t);
+                ov_ldv<VEC>(src + (int64_t)r * ldb + boff, v[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += w[t] * v[t][j];
+        }
+    }
+}
+
+// Gene part of the backward: for every panel node p, D[p, :] = sum over the genes g of column p of
+// W[g, p] * D[g, :].  One wave per (node, 64*VEC columns).
+template <int VEC>
+__global__ __launch_bounds__(256) void ov_dec_bwd_gene_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_split,
+                                                             const int32_t* __restrict__ csc_row, const int32_t* __restrict__ csc_k,
+                                                             const float* __restrict__ vals, float* __restrict__ d, int C, int ldb) {
+    const int node = blockIdx.x * 4 + ov_wave_id();
+    if (node >= C) return;
+    const int lane = ov_lane();
+    const int b0 = blockIdx.y * (64 * VEC) + lane * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    ov_gather_rows_acc<VEC, true>(acc, csc_split[node], cscptr[node + 1], csc_row, csc_k, vals, d, ldb, b0, lane);
+    ov_stv<VEC>(d + (int64_t)node * ldb + b0, acc);
+}
+
+// Gene layer, tiled: a workgroup of 8 waves takes 32 genes x (64*VEC) batch columns.  The x tile is
+// read in full 128-B row segments (x is sample-major) and transposed through LDS, so the ELBO
+// epilogue reads x feature-major like everything else; each wave then runs 4 gene rows.
+// MODE 1: training (D = 2 (recon - x), partial sums of squares); MODE 2: inference (recon is
+// transposed back through the same LDS tile and stored sample-major in 128-B segments).
+#define OV_GT_GENES 32
+template <int VEC, int MODE>
+__global__ __launch_bounds__(512) void ov_dec_gene_tile_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                             const float* __restrict__ vals, const float* __restrict__ bias,
+                                                             const float* __restrict__ act, int B, int ldb,
+                                                             const float* __restrict__ x, const int32_t* __restrict__ xidx, int G,
+                                                             float* __restrict__ d, float* __restrict__ rec_part,
+                                                             float* __restrict__ rec_out, int64_t rec_ld, int C) {
+    constexpr int NB = 64 * VEC;      // batch columns of this tile
+    constexpr int LD = NB + 1;        // odd row length: conflict-free transposed writes
+    constexpr int Q = OV_GT_GENES / 4;
+    __shared__ float xs[OV_GT_GENES * LD];
+    __shared__ float red[8];
+    const int g0 = blockIdx.x * OV_GT_GENES;
+    const int bt0 = blockIdx.y * NB;
+    const int lane = ov_lane();
+    const int wave = ov_wave_id();
+    if (MODE == 1) {
+        for (int u = threadIdx.x; u < NB * Q; u += 512) {
+            const int b = u / Q, j = u % Q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (bt0 + b < B && g0 + 4 * j < G) {
+                const int64_t r = xidx ? (int64_t)xidx[bt0 + b] : (int64_t)(bt0 + b);
+                v = *reinterpret_cast<const f32x4*>(x + r * G + g0 + 4 * j);
+            }
+            xs[(4 * j + 0) * LD + b] = v.x;
+            xs[(4 * j + 1) * LD + b] = v.y;
+            xs[(4 * j + 2) * LD + b] = v.z;
+            xs[(4 * j + 3) * LD + b] = v.w;
+        }
+        __syncthreads();
+    }
+    float sq = 0.f;
+    const int bl = lane * VEC;
+    for (int gl = wave; gl < OV_GT_GENES; gl += 8) {
+        const int g = g0 + gl;
+        if (g >= G) break;                       // wave-uniform
+        const int node = C + g;
+        float acc[VEC];
+        const float bv = bias[node];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = bv;
+        ov_gather_rows_acc<VEC, false>(acc, rowptr[node], rowptr[node + 1], colidx, nullptr, vals, act, ldb, bt0 + bl, lane);
+        if (MODE == 1) {
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float dv = 0.f;
+                if (bt0 + bl + j < B) {
+                    dv = acc[j] - xs[gl * LD + bl + j];
+                    sq += dv * dv;
+                }
+                o[j] = 2.f * dv;
+            }
+            ov_stv<VEC>(d + (int64_t)node * ldb + bt0 + bl, o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) xs[gl * LD + bl + j] = acc[j];
+        }
+    }
+    if (MODE == 1) {
+        sq = ov_wave_sum(sq);
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int i = 0; i < 8; ++i) t += red[i];
+            rec_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+        }
+    } else {
+        __syncthreads();
+        for (int u = threadIdx.x; u < NB * Q; u += 512) {
+            const int b = u / Q, j = u % Q;
+            if (bt0 + b < B && g0 + 4 * j < G) {
+                f32x4 v;
+                v.x = xs[(4 * j + 0) * LD + b];
+                v.y = xs[(4 * j + 1) * LD + b];
+                v.z = xs[(4 * j + 2) * LD + b];
+                v.w = xs[(4 * j + 3) * LD + b];
+                *reinterpret_cast<f32x4*>(rec_out + (int64_t)(bt0 + b) * rec_ld + g0 + 4 * j) = v;
+            }
+        }
+    }
+}
+
 // Backward data, one wave per (panel node of the level, batch chunk), CSC gather:
 //   D[p, :] = sum_q vals[csc_k[q]] * D[csc_row[q], :]
 template <int VEC>
@@ -564,14 +849,31 @@ __global__ __launch_bounds__(256) void ov_dec_wgrad_kernel(const int32_t* __rest
     gb = ov_wave_sum(gb);
     for (int kb = k0; kb < k1; kb += 64) {
         const int cnt = min(64, k1 - kb);
+        const int my_c = lane < cnt ? colidx[kb + lane] : 0;    // one coalesced index load per 64 entries
         float mine = 0.f;
-        for (int j = 0; j < cnt; ++j) {
-            const int c = colidx[kb + j];
-            const float* ar = act + (int64_t)c * ldb;
-            float s = 0.f;
-            for (int b = lane; b < ldb; b += 64) s += dr[b] * ar[b];
-            s = ov_wave_sum(s);
-            if (lane == j) mine = s;
+        int j = 0;
+        for (; j + 4 <= cnt; j += 4) {          // four row dots in flight
+            const float* a0 = act + (int64_t)OV_RL_I(my_c, j) * ldb;
+            const float* a1 = act + (int64_t)OV_RL_I(my_c, j + 1) * ldb;
+            const float* a2 = act + (int64_t)OV_RL_I(my_c, j + 2) * ldb;
+            const float* a3 = act + (int64_t)OV_RL_I(my_c, j + 3) * ldb;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int b = lane; b < ldb; b += 64) {
+                const float dv = dr[b];
+                s0 += dv * a0[b]; s1 += dv * a1[b]; s2 += dv * a2[b]; s3 += dv * a3[b];
+            }
+            s0 = ov_wave_sum(s0); s1 = ov_wave_sum(s1); s2 = ov_wave_sum(s2); s3 = ov_wave_sum(s3);
+            mine = lane == j ? s0 : mine;
+            mine = lane == j + 1 ? s1 : mine;
+            mine = lane == j + 2 ? s2 : mine;
+            mine = lane == j + 3 ? s3 : mine;
+        }
+        for (; j < cnt; ++j) {
+            const float* ar = act + (int64_t)OV_RL_I(my_c, j) * ldb;
+            float sacc = 0.f;
+            for (int b = lane; b < ldb; b += 64) sacc += dr[b] * ar[b];
+            sacc = ov_wave_sum(sacc);
+            mine = lane == j ? sacc : mine;
         }
         if (lane < cnt) {
             const int k = kb + lane;
@@ -756,7 +1058,7 @@ static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
         ontovae_set_error("ctx: bad dims G=%d L=%d C=%d K=%d nu=%d", d.G, d.L, d.C, d.K, d.nu);
         return ONTOVAE_EINVAL;
     }
-    if (!c->P || !c->rowptr || !c->colidx || !c->cscptr || !c->csc_row || !c->csc_k || !c->level_begin || !c->level_end ||
+    if (!c->P || !c->rowptr || !c->colidx || !c->cscptr || !c->csc_row || !c->csc_k || !c->csc_split || !c->level_begin || !c->level_end ||
         !c->workspace || !c->bn_rmean || !c->bn_rvar || !c->bn_nbt) {
         ontovae_set_error("ctx: a required pointer is NULL");
         return ONTOVAE_EINVAL;
@@ -876,13 +1178,99 @@ static int ov_dec_fwd_level(OvStep& s, int nb, int ne, float* rec_out, int64_t r
     return ONTOVAE_OK;
 }
 
-static int ov_dec_forward_terms(OvStep& s) {
-    const ontovae_dims_t& d = s.c->dims;
-    for (int lvl = 1; lvl < d.K; ++lvl) {
-        int rc = ov_dec_fwd_level<0>(s, s.c->level_begin[lvl], s.c->level_end[lvl], nullptr, 0);
-        if (rc) return rc;
-    }
+// batch columns per workgroup of the fused term-level kernels: the [C][BT] fp32 panel must fit LDS
+static int ov_fused_bt(const ontovae_ctx_t* c) {
+    const ontovae_dims_t& d = c->dims;
+    if (d.K > OV_MAX_LEVELS || d.K < 2 || (c->flags & ONTOVAE_FLAG_LEVEL_LAUNCHES)) return 0;
+    const ontovae_sell_t& f = c->sell_fwd;
+    const ontovae_sell_t& b = c->sell_bwd;
+    if (f.n_slices < 1 || b.n_slices < 1 || f.n_levels != d.K - 1 || b.n_levels != d.K || !f.node || !f.info || !f.chunk0 ||
+        !f.idx || !f.k || !f.w || !f.bias || !b.node || !b.info || !b.chunk0 || !b.idx || !b.k || !b.w || !f.level_first ||
+        !f.level_count || !b.level_first || !b.level_count)
+        return 0;
+    const int64_t lds = 160 * 1024;
+    if ((int64_t)d.C * 16 <= lds) return 4;
+    if ((int64_t)d.C * 8 <= lds) return 2;
+    if ((int64_t)d.C * 4 <= lds) return 1;
+    return 0;
+}
+
+template <typename KernelT>
+static int ov_set_lds(KernelT kernel, size_t bytes) {
+    OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return ONTOVAE_OK;
+}
+
+// SELL weight copies <- parameter buffer; called once per pass before the first chain kernel
+static int ov_sell_refresh(OvStep& s) {
+    const ontovae_ctx_t* c = s.c;
+    if (ov_fused_bt(c) == 0) return ONTOVAE_OK;
+    const ontovae_sell_t& f = c->sell_fwd;
+    const ontovae_sell_t& b = c->sell_bwd;
+    const int nf = f.n_chunks * 512, nbf = f.n_slices * 64, nb = b.n_chunks * 512;
+    const int blocks = std::min(512, (std::max(nf, nb) + 255) / 256);
+    hipLaunchKernelGGL(ov_sell_refresh_kernel, dim3(blocks), dim3(256), 0, s.st, c->P + c->lay.dec_vals, c->P + c->lay.dec_bias,
+                       f.k, f.w, nf, f.node, f.bias, nbf, b.k, b.w, nb);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+static int ov_dec_forward_terms(OvStep& s) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    const int bt = ov_fused_bt(c);
+    if (bt == 0) {
+        for (int lvl = 1; lvl < d.K; ++lvl) {
+            int rc = ov_dec_fwd_level<0>(s, c->level_begin[lvl], c->level_end[lvl], nullptr, 0);
+            if (rc) return rc;
+        }
+        return ONTOVAE_OK;
+    }
+    int rc;
+    if ((rc = ov_sell_refresh(s))) return rc;
+    const ontovae_sell_t& f = c->sell_fwd;
+    OvLevels lv;
+    lv.n = f.n_levels;
+    for (int i = 0; i < lv.n; ++i) { lv.first[i] = f.level_first[i]; lv.count[i] = f.level_count[i]; }
+    const size_t lds = (size_t)d.C * bt * sizeof(float);
+    OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
+#define OV_TF(BT)                                                                                                     \
+    if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false>, lds))) return rc;                                             \
+    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false>), dim3(s.ldb / BT), dim3(1024), lds, s.st, f.node, f.info, f.chunk0, \
+                       f.idx, f.w, f.bias, s.ws.act, s.ldb, d.C - d.L, d.C, f.all_single_chunk, lv)
+    if (bt == 4) { OV_TF(4); } else if (bt == 2) { OV_TF(2); } else { OV_TF(1); }
+#undef OV_TF
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+// gene layer: tiled kernel when x can be read in aligned 16-B pieces, row-per-wave kernel otherwise
+template <int MODE>
+static int ov_dec_gene(OvStep& s, float* rec_out, int64_t rec_ld) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    bool tiled = (d.G % 4 == 0) && !(c->flags & ONTOVAE_FLAG_ROW_GENE_LAYER);
+    if (MODE == 1) tiled = tiled && ov_al16(s.x) && (s.xld % 4 == 0);
+    if (MODE == 2) tiled = tiled && ov_al16(rec_out) && (rec_ld % 4 == 0);
+    if (!tiled) return ov_dec_fwd_level<MODE>(s, d.C, d.C + d.G, rec_out, rec_ld);
+    dim3 grid((d.G + OV_GT_GENES - 1) / OV_GT_GENES, s.nchunk);
+    const float* vals = c->P + c->lay.dec_vals;
+    const float* bias = c->P + c->lay.dec_bias;
+    OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_GENE, s.st);
+#define OV_GT(V)                                                                                                       \
+    hipLaunchKernelGGL((ov_dec_gene_tile_kernel<V, MODE>), grid, dim3(512), 0, s.st, c->rowptr, c->colidx, vals, bias, s.ws.act, \
+                       s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C)
+    if (s.vec == 1) OV_GT(1); else if (s.vec == 2) OV_GT(2); else OV_GT(4);
+#undef OV_GT
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+// number of sum-of-squares partials the gene layer wrote (must match ov_dec_gene<1>)
+static int ov_nrec(const OvStep& s) {
+    const ontovae_dims_t& d = s.c->dims;
+    const bool tiled = (d.G % 4 == 0) && !(s.c->flags & ONTOVAE_FLAG_ROW_GENE_LAYER) && ov_al16(s.x) && (s.xld % 4 == 0);
+    return (tiled ? (d.G + OV_GT_GENES - 1) / OV_GT_GENES : (d.G + 3) / 4) * s.nchunk;
 }
 
 static int ov_dec_bwd_level(OvStep& s, int nb, int ne) {
@@ -894,6 +1282,40 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne) {
 #define OV_DB(V) hipLaunchKernelGGL((ov_dec_bwd_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_row, c->csc_k, vals, s.ws.d, nb, ne, s.ldb)
     if (s.vec == 1) OV_DB(1); else if (s.vec == 2) OV_DB(2); else OV_DB(4);
 #undef OV_DB
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+static int ov_dec_backward(OvStep& s) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    const int bt = ov_fused_bt(c);
+    int rc;
+    if (bt == 0) {
+        for (int lvl = d.K - 1; lvl >= 0; --lvl)
+            if ((rc = ov_dec_bwd_level(s, c->level_begin[lvl], c->level_end[lvl]))) return rc;
+        return ONTOVAE_OK;
+    }
+    const float* vals = c->P + c->lay.dec_vals;
+    OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
+    {
+        dim3 grid((d.C + 3) / 4, s.nchunk);
+#define OV_BG(V) hipLaunchKernelGGL((ov_dec_bwd_gene_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row, c->csc_k, vals, s.ws.d, d.C, s.ldb)
+        if (s.vec == 1) OV_BG(1); else if (s.vec == 2) OV_BG(2); else OV_BG(4);
+#undef OV_BG
+        OV_LAUNCH_CHECK();
+    }
+    const ontovae_sell_t& sb = c->sell_bwd;
+    OvLevels lv;
+    lv.n = sb.n_levels;
+    for (int i = 0; i < lv.n; ++i) { lv.first[i] = sb.level_first[i]; lv.count[i] = sb.level_count[i]; }
+    const size_t lds = (size_t)d.C * bt * sizeof(float);
+#define OV_TB(BT)                                                                                                     \
+    if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true>, lds))) return rc;                                              \
+    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true>), dim3(s.ldb / BT), dim3(1024), lds, s.st, sb.node, sb.info, sb.chunk0, \
+                       sb.idx, sb.w, (const float*)nullptr, s.ws.d, s.ldb, 0, 0, sb.all_single_chunk, lv)
+    if (bt == 4) { OV_TB(4); } else if (bt == 2) { OV_TB(2); } else { OV_TB(1); }
+#undef OV_TB
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
@@ -952,7 +1374,7 @@ extern "C" int ontovae_forward(const ontovae_ctx_t* ctx, const float* x, const i
     if (log_var && (rc = ov_transpose_out(s, s.ws.mulv + (int64_t)d.L * s.ldb, d.L, log_var, d.L))) return rc;
     if (recon) {
         if ((rc = ov_dec_forward_terms(s))) return rc;
-        if ((rc = ov_dec_fwd_level<2>(s, d.C, d.C + d.G, recon, d.G))) return rc;
+        if ((rc = ov_dec_gene<2>(s, recon, d.G))) return rc;
     }
     return ONTOVAE_OK;
 }
@@ -968,8 +1390,8 @@ extern "C" int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const
     int nkl = 0;
     if ((rc = ov_encode(s, eps, 0, rng_offset, OV_RNG_EPS, 1, &nkl))) return rc;
     if ((rc = ov_dec_forward_terms(s))) return rc;
-    if ((rc = ov_dec_fwd_level<1>(s, d.C, d.C + d.G, nullptr, 0))) return rc;
-    return ov_loss_finalize(s, ((d.G + 3) / 4) * s.nchunk, nkl, kl_coeff, loss_out);
+    if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
+    return ov_loss_finalize(s, ov_nrec(s), nkl, kl_coeff, loss_out);
 }
 
 static int ov_act_out(OvStep& s, int lvl_from, int lvl_to, float* act_out, int64_t act_ld) {
@@ -1005,7 +1427,7 @@ extern "C" int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const
     if ((rc = ov_reparam(s, eps2, 0, rng_offset, OV_RNG_EPS2, 0, nullptr))) return rc;  // draw #2 feeds the decoder
     if ((rc = ov_dec_forward_terms(s))) return rc;
     if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld))) return rc;
-    if (rec_out && (rc = ov_dec_fwd_level<2>(s, d.C, d.C + d.G, rec_out, rec_ld))) return rc;
+    if (rec_out && (rc = ov_dec_gene<2>(s, rec_out, rec_ld))) return rc;
     return ONTOVAE_OK;
 }
 
@@ -1023,7 +1445,7 @@ extern "C" int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z,
     OV_LAUNCH_CHECK();
     if ((rc = ov_dec_forward_terms(s))) return rc;
     if (act_out && (rc = ov_act_out(s, 0, d.K, act_out, act_ld))) return rc;
-    if (rec_out && (rc = ov_dec_fwd_level<2>(s, d.C, d.C + d.G, rec_out, rec_ld))) return rc;
+    if (rec_out && (rc = ov_dec_gene<2>(s, rec_out, rec_ld))) return rc;
     return ONTOVAE_OK;
 }
 
@@ -1042,10 +1464,9 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     if ((rc = ov_heads_fwd(s))) return rc;
     if ((rc = ov_reparam(s, eps, 1, rng_off, OV_RNG_EPS, 1, &nkl))) return rc;
     if ((rc = ov_dec_forward_terms(s))) return rc;
-    if ((rc = ov_dec_fwd_level<1>(s, d.C, d.C + d.G, nullptr, 0))) return rc;
-    for (int lvl = d.K - 1; lvl >= 0; --lvl)
-        if ((rc = ov_dec_bwd_level(s, c->level_begin[lvl], c->level_end[lvl]))) return rc;
-    if ((rc = ov_loss_finalize(s, ((d.G + 3) / 4) * s.nchunk, nkl, kc, loss_out))) return rc;
+    if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
+    if ((rc = ov_dec_backward(s))) return rc;
+    if ((rc = ov_loss_finalize(s, ov_nrec(s), nkl, kc, loss_out))) return rc;
     // decoder weight gradients (+ AdamW + clamp)
     {
         const int n_term_rows = d.C - d.L;

@@ -35,7 +35,77 @@ struct ontovae_plan {
     std::vector<int32_t> rowptr, colidx, cscptr, csc_row, csc_k;
     std::vector<int32_t> e_layer, e_row, e_col;   // dense coordinates per packed entry
     std::vector<int64_t> layer_k0;     // first packed entry of each layer (K+1)
+    // level-scheduled SELL-64 form of the term layers, [0] forward (CSR rows), [1] backward (term part
+    // of the CSC columns)
+    struct Sell {
+        std::vector<int32_t> level_first, level_count;   // slices of each level, in processing order
+        std::vector<int32_t> node, info;                 // per lane of each slice
+        std::vector<int32_t> chunk0;                     // first 64x8 chunk of each slice (+ sentinel)
+        std::vector<int32_t> idx, k;                     // per chunk: [8][64] gather node / packed-weight index
+        int32_t all_single = 1;
+    } sell[2];
 };
+
+static void build_sell(ontovae_plan* p, int dir) {
+    const int K = p->dims.K;
+    const int32_t C = p->dims.C;
+    ontovae_plan::Sell& S = p->sell[dir];
+    std::vector<int> levels;
+    if (dir == 0) for (int d = 1; d < K; ++d) levels.push_back(d);
+    else for (int d = K - 1; d >= 0; --d) levels.push_back(d);
+    auto lo = [&](int32_t n) { return dir == 0 ? p->rowptr[n] : p->cscptr[n]; };
+    auto hi = [&](int32_t n) {
+        if (dir == 0) return p->rowptr[n + 1];
+        const int32_t* b = p->csc_row.data() + p->cscptr[n];
+        const int32_t* e = p->csc_row.data() + p->cscptr[n + 1];
+        return (int32_t)(std::lower_bound(b, e, C) - p->csc_row.data());
+    };
+    S.chunk0.push_back(0);
+    int32_t nchunks = 0;
+    for (int d : levels) {
+        std::vector<std::pair<int32_t, int32_t>> nodes;   // (len, node)
+        for (int32_t n = p->level_begin[d]; n < p->level_end[d]; ++n) nodes.push_back({hi(n) - lo(n), n});
+        std::stable_sort(nodes.begin(), nodes.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        S.level_first.push_back((int32_t)(S.node.size() / 64));
+        size_t i = 0;
+        while (i < nodes.size()) {
+            // lanes per node and chunks per lane of this slice, from its longest (first) node
+            const int32_t len0 = nodes[i].first;
+            int g = 1;
+            while (g < 64 && (int64_t)g * 8 < len0) g *= 2;
+            const int32_t R = std::max<int32_t>(1, (len0 + g * 8 - 1) / (g * 8));
+            if (R > 1) S.all_single = 0;
+            int lg = 0;
+            while ((1 << lg) < g) ++lg;
+            const size_t lane0 = S.node.size();
+            S.node.resize(lane0 + 64, -1);
+            S.info.resize(lane0 + 64, lg << 16);
+            const size_t e0 = S.idx.size();
+            S.idx.resize(e0 + (size_t)R * 512, 0);
+            S.k.resize(e0 + (size_t)R * 512, -1);
+            for (int slot = 0; slot < 64 / g && i < nodes.size(); ++slot, ++i) {
+                const int32_t len = nodes[i].first, n = nodes[i].second;
+                const int32_t base = lo(n);
+                for (int gl = 0; gl < g; ++gl) {
+                    const int lane = slot * g + gl;
+                    const int32_t first = gl * R * 8;                       // this lane's entries: [first, first + R*8)
+                    const int32_t cnt = std::max<int32_t>(0, std::min<int32_t>(len - first, R * 8));
+                    S.node[lane0 + lane] = n;
+                    S.info[lane0 + lane] = cnt | (lg << 16) | ((gl == g - 1) ? (1 << 24) : 0);
+                    for (int32_t e = 0; e < cnt; ++e) {
+                        const int32_t q = base + first + e;
+                        const size_t pos = e0 + (size_t)(e / 8) * 512 + (size_t)(e % 8) * 64 + lane;
+                        S.idx[pos] = dir == 0 ? p->colidx[q] : p->csc_row[q];
+                        S.k[pos] = dir == 0 ? q : p->csc_k[q];
+                    }
+                }
+            }
+            nchunks += R;
+            S.chunk0.push_back(nchunks);
+        }
+        S.level_count.push_back((int32_t)(S.node.size() / 64) - S.level_first.back());
+    }
+}
 
 struct Link { int32_t layer, row, col; };
 
@@ -193,6 +263,10 @@ static int build(int32_t K, const int32_t* rows, const int32_t* cols, int32_t nu
                 p->csc_k[pos] = q;
             }
     }
+    p->dims.C = (int32_t)C;
+    p->dims.K = K;
+    build_sell(p, 0);
+    build_sell(p, 1);
     p->dims.G = (int32_t)G;
     p->dims.T = (int32_t)T;
     p->dims.K = K;
@@ -269,6 +343,45 @@ extern "C" int ontovae_plan_export(const ontovae_plan_t* plan, int32_t* rowptr, 
     cp(cscptr, plan->cscptr);
     cp(csc_row, plan->csc_row);
     cp(csc_k, plan->csc_k);
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_sell_sizes(const ontovae_plan_t* plan, int32_t dir, int32_t* n_levels, int32_t* n_slices,
+                                       int32_t* n_chunks, int32_t* all_single_chunk) {
+    if (!plan || dir < 0 || dir > 1) return ONTOVAE_EINVAL;
+    const ontovae_plan::Sell& S = plan->sell[dir];
+    if (n_levels) *n_levels = (int32_t)S.level_first.size();
+    if (n_slices) *n_slices = (int32_t)(S.node.size() / 64);
+    if (n_chunks) *n_chunks = S.chunk0.back();
+    if (all_single_chunk) *all_single_chunk = S.all_single;
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_sell_export(const ontovae_plan_t* plan, int32_t dir, int32_t* level_first, int32_t* level_count,
+                                        int32_t* node, int32_t* info, int32_t* chunk0, int32_t* idx, int32_t* k) {
+    if (!plan || dir < 0 || dir > 1) return ONTOVAE_EINVAL;
+    const ontovae_plan::Sell& S = plan->sell[dir];
+    auto cp = [](int32_t* dst, const std::vector<int32_t>& v) {
+        if (dst && !v.empty()) std::memcpy(dst, v.data(), sizeof(int32_t) * v.size());
+    };
+    cp(level_first, S.level_first);
+    cp(level_count, S.level_count);
+    cp(node, S.node);
+    cp(info, S.info);
+    cp(chunk0, S.chunk0);
+    cp(idx, S.idx);
+    cp(k, S.k);
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_csc_split(const ontovae_plan_t* plan, int32_t* csc_split) {
+    if (!plan || !csc_split) return ONTOVAE_EINVAL;
+    const int32_t C = plan->dims.C;
+    for (int32_t p = 0; p < C; ++p) {
+        const int32_t* b = plan->csc_row.data() + plan->cscptr[p];
+        const int32_t* e = plan->csc_row.data() + plan->cscptr[p + 1];
+        csc_split[p] = (int32_t)(std::lower_bound(b, e, C) - plan->csc_row.data());
+    }
     return ONTOVAE_OK;
 }
 

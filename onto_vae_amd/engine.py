@@ -48,6 +48,7 @@ class Engine:
         self._idx = None
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self.rng_offset = 0
+        self.flags = 0          # _lib FLAG_* bits: force the general-purpose kernel variants (tests)
         self._upload_plan()
 
     # ------------------------------------------------------------------ views of the flat buffer
@@ -117,8 +118,14 @@ class Engine:
         p = self.plan
         dev = self.device
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self._sell = []
+        for sd in p.sell:
+            dv = {f: t(sd[f]) for f in ("node", "info", "chunk0", "idx", "k")}
+            dv["w"] = torch.zeros(max(sd["n_chunks"], 1) * 512, dtype=torch.float32, device=dev)
+            dv["bias"] = torch.zeros(max(sd["n_slices"], 1) * 64, dtype=torch.float32, device=dev)
+            self._sell.append(dv)
         self._idx = dict(rowptr=t(p.rowptr), colidx=t(p.colidx), cscptr=t(p.cscptr), csc_row=t(p.csc_row),
-                         csc_k=t(p.csc_k), er=t(p.entry_row), ec=t(p.entry_col))
+                         csc_k=t(p.csc_k), csc_split=t(p.csc_split), er=t(p.entry_row), ec=t(p.entry_col))
         self._ctx = None
 
     def to(self, device):
@@ -174,14 +181,24 @@ class Engine:
             i = self._idx
             c.rowptr, c.colidx = _ptr(i["rowptr"]), _ptr(i["colidx"])
             c.cscptr, c.csc_row, c.csc_k = _ptr(i["cscptr"]), _ptr(i["csc_row"]), _ptr(i["csc_k"])
+            c.csc_split = _ptr(i["csc_split"])
             c.level_begin = self.plan.level_begin.ctypes.data_as(_lib.c_i32p)
             c.level_end = self.plan.level_end.ctypes.data_as(_lib.c_i32p)
+            for name, sd, dev in (("sell_fwd", self.plan.sell[0], self._sell[0]), ("sell_bwd", self.plan.sell[1], self._sell[1])):
+                t = getattr(c, name)
+                t.n_levels, t.n_slices, t.n_chunks = sd["n_levels"], sd["n_slices"], sd["n_chunks"]
+                t.all_single_chunk = sd["all_single_chunk"]
+                t.level_first = sd["level_first"].ctypes.data_as(_lib.c_i32p)
+                t.level_count = sd["level_count"].ctypes.data_as(_lib.c_i32p)
+                for f in ("node", "info", "chunk0", "idx", "k", "w", "bias"):
+                    setattr(t, f, _ptr(dev[f]))
             base = self._ws.data_ptr()
             aligned = (base + 255) // 256 * 256
             c.workspace = C.c_void_p(aligned)
             c.workspace_bytes = self._ws.numel() - (aligned - base)
             c.max_batch = self.max_batch
             c.drop, c.z_drop, c.seed = self.drop, self.z_drop, self.seed
+            c.flags = self.flags
             self._ctx = c
         return self._ctx
 

@@ -63,6 +63,9 @@ class MaskPlan:
         self.csc_k = np.zeros(n, dtype=np.int32)
         _lib.check(L.ontovae_plan_export(handle, _i32p(self.rowptr), _i32p(self.colidx), _i32p(self.cscptr),
                                          _i32p(self.csc_row), _i32p(self.csc_k)), "plan export")
+        self.csc_split = np.zeros(max(self.C, 1), dtype=np.int32)
+        _lib.check(L.ontovae_plan_csc_split(handle, _i32p(self.csc_split)), "plan csc split")
+        self.sell = [self._export_sell(d) for d in (0, 1)]
         self.entry_layer = np.zeros(n, dtype=np.int32)
         self.entry_row = np.zeros(n, dtype=np.int32)
         self.entry_col = np.zeros(n, dtype=np.int32)
@@ -88,6 +91,19 @@ class MaskPlan:
             cin += cout if i < self.K - 1 else 0
         self.layout = _lib.Layout()
         _lib.check(L.ontovae_param_layout(C.byref(self.dims), C.byref(self.layout)), "param layout")
+
+    def _export_sell(self, direction):
+        """Level-scheduled SELL-64 form of the term layers (see ontovae_sell_t in the header)."""
+        L, h = self._L, self._h
+        nl, ns, nc, single = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(L.ontovae_plan_sell_sizes(h, direction, C.byref(nl), C.byref(ns), C.byref(nc), C.byref(single)), "sell sizes")
+        z = lambda n: np.zeros(max(int(n), 1), dtype=np.int32)
+        d = dict(n_levels=nl.value, n_slices=ns.value, n_chunks=nc.value, all_single_chunk=single.value,
+                 level_first=z(nl.value), level_count=z(nl.value), node=z(ns.value * 64), info=z(ns.value * 64),
+                 chunk0=z(ns.value + 1), idx=z(nc.value * 512), k=z(nc.value * 512))
+        _lib.check(L.ontovae_plan_sell_export(h, direction, _i32p(d["level_first"]), _i32p(d["level_count"]), _i32p(d["node"]),
+                                              _i32p(d["info"]), _i32p(d["chunk0"]), _i32p(d["idx"]), _i32p(d["k"])), "sell export")
+        return d
 
     def unpack_mask(self, layer):
         """Expanded dense 0/1 mask of layer i, uint8 [out_i, in_i] (== OntoDecoder.masks[i])."""

@@ -194,8 +194,9 @@ def test_train_vs_oracle_batch_sizes(B):
     check_params(hip_state(model), o.state_dict(), 3 * lr, rtol=2e-4, atol=2e-6, outliers=0.01)
 
 
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
 @pytest.mark.parametrize("B", [128, 200, 37])
-def test_gradients_vs_oracle(B):
+def test_gradients_vs_oracle(B, flags):
     """Raw gradients (apply_update=0 -> flat buffer) against the oracle's hand-written backward:
     every tensor within 2e-5 of its own scale (fp32 summation-order noise is ~2e-6)."""
     from ontovae_oracle import OracleOntoVAE
@@ -208,6 +209,8 @@ def test_gradients_vs_oracle(B):
     rec, kl, loss, g = o.gradients(x, eps, 1e-4)
     model, _ = make_model(masks, 3, sd)
     e = model._engine
+    e.flags = flags          # 1: per-level launches, 2: row-per-wave gene layer (the general-purpose variants)
+    e.invalidate()
     out = torch.zeros(3, device="cuda")
     e.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), 1e-4, None, out, apply_update=False)
     np.testing.assert_allclose(out.cpu().numpy(), [rec, kl, loss], rtol=REL)

@@ -94,3 +94,71 @@ def test_pack_rejects_bad_input():
         MaskPlan(bad, 3)
     with pytest.raises(ValueError):
         MaskPlan(neuronnum=1, links=([0], [99], [0]), shapes=[m.shape for m in good])
+
+
+def check_sell(plan):
+    """The level-scheduled SELL-64 form holds exactly the term-layer entries of the CSR (forward)
+    and of the term part of the CSC (backward), every node once per direction, levels in order."""
+    C = plan.C
+    for direction, sd in enumerate(plan.sell):
+        ns, nl = sd["n_slices"], sd["n_levels"]
+        levels = list(range(1, plan.K)) if direction == 0 else list(range(plan.K - 1, -1, -1))
+        assert nl == len(levels)
+        seen = {}
+        for li, d in enumerate(levels):
+            f, c = int(sd["level_first"][li]), int(sd["level_count"][li])
+            want_nodes = set(range(plan.level_begin[d], plan.level_end[d]))
+            got_nodes = set()
+            for sl in range(f, f + c):
+                c0, c1 = int(sd["chunk0"][sl]), int(sd["chunk0"][sl + 1])
+                info = sd["info"][sl * 64:(sl + 1) * 64]
+                node = sd["node"][sl * 64:(sl + 1) * 64]
+                lg = (info >> 16) & 7
+                assert len(set(lg.tolist())) == 1
+                g = 1 << int(lg[0])
+                for lane in range(64):
+                    n = int(node[lane])
+                    cnt = int(info[lane] & 0xFFFF)
+                    writer = (int(info[lane]) >> 24) & 1
+                    if n < 0:
+                        assert cnt == 0 and not writer
+                        continue
+                    assert writer == (lane % g == g - 1)
+                    assert cnt <= (c1 - c0) * 8
+                    got_nodes.add(n)
+                    for e in range(cnt):
+                        pos = (c0 + e // 8) * 512 + (e % 8) * 64 + lane
+                        seen.setdefault(n, []).append((int(sd["idx"][pos]), int(sd["k"][pos])))
+                # lanes of one node are adjacent and aligned
+                for lane in range(0, 64, g):
+                    assert len(set(node[lane:lane + g].tolist())) == 1
+            assert got_nodes == want_nodes, (direction, d)
+        if sd["all_single_chunk"]:
+            assert np.array_equal(sd["chunk0"][:ns + 1], np.arange(ns + 1))
+        for d in levels:
+            for n in range(plan.level_begin[d], plan.level_end[d]):
+                if direction == 0:
+                    ks = range(plan.rowptr[n], plan.rowptr[n + 1])
+                    want = [(int(plan.colidx[k]), k) for k in ks]
+                else:
+                    qs = range(plan.cscptr[n], plan.csc_split[n])
+                    want = [(int(plan.csc_row[q]), int(plan.csc_k[q])) for q in qs]
+                    assert all(r < C for r, _ in want)
+                assert seen.get(n, []) == want, (direction, n)
+
+
+def test_sell_golden_cases(case):
+    _, fx, masks = case
+    check_sell(MaskPlan(masks, int(fx["nu"])))
+
+
+def test_sell_long_rows():
+    """Terms with hundreds of parents/children: many lanes per node and multi-chunk lanes."""
+    rng = np.random.RandomState(0)
+    n0, n1, n2, G = 700, 3, 2, 12
+    m0 = (rng.rand(n1, n0) < 0.9).astype(np.int64)          # level-1 terms with ~630 parents each
+    m1 = (rng.rand(n2, n1 + n0) < 0.5).astype(np.int64)
+    m2 = (rng.rand(G, n2 + n1 + n0) < 0.05).astype(np.int64)
+    plan = MaskPlan([m0, m1, m2], 3)
+    assert not plan.sell[0]["all_single_chunk"]
+    check_sell(plan)
