@@ -8,12 +8,22 @@
 // row(i) = bgather ? bgather[i] : i is the batcher's row indirection into the HBM-resident dataset.
 //
 // Fragments go straight from global memory (L2) to registers: fp32 MFMA runs at 64 cycles per
-// 32x32x2 per SIMD, so per k-step of 8 a wave needs MT + NT 16-byte loads per 4*MT*NT MFMAs and the
-// load path is nowhere near critical; there is no LDS stage and no barrier.  The lane -> (row, k)
-// map of one k-step of 8: lane (i = lane & 31, h = lane >> 5) supplies k = k0 + 4h + t to MFMA t
-// (t = 0..3), for A and B alike, which is all the instruction needs.
+// 32x32x2 per SIMD, so the arithmetic is slow enough that no LDS stage is needed as long as the
+// loads are issued far enough ahead.  Two things provide that distance:
+//   * UK k-steps (of 8) are loaded as one batch, and the next batch is issued before the current
+//     one's MFMAs (double buffering in registers);
+//   * a wave tile of MT x NT 32x32 blocks gives 4*MT*NT MFMAs per k-step (3072 cycles for the
+//     96x128 tile of the encoder forward), more than an L2 round trip.
+// The lane -> (row, k) map of one k-step of 8: lane (i = lane & 31, h = lane >> 5) supplies
+// k = k0 + 4h + t to MFMA t (t = 0..3), for A and B alike, which is all the instruction needs.
 //
-// grid = (ceil(N / (64 NT)), ceil(M / (64 MT)), S); blockIdx.z is the split-K slab.
+// Work decomposition (256 threads = 4 waves):
+//   KW == 1: the waves own a 2x2 arrangement of wave tiles, block tile (64 MT) x (64 NT);
+//   KW == 4: the waves share ONE wave tile and split the block's K range four ways; the partial
+//            tiles are combined through LDS (tree: 2,3 -> 0,1; 1 -> 0) and wave 0 runs the epilogue.
+//            This is how skinny products (K >> M*N/chip) fill the chip without a slab per wave.
+// blockIdx.z is a further split of K across workgroups; its partial results go to slabs
+// (EPI_STORE) that the consumer sums.
 #ifndef ONTOVAE_GEMM_H
 #define ONTOVAE_GEMM_H
 
@@ -31,7 +41,7 @@ struct OvGemm {
     float* C;             // EPI_STORE/BIAS: output (+ z * slab_stride); EPI_ADAMW: the parameter
     int64_t ldc;
     int64_t slab_stride;
-    int kchunk;           // multiple of 8
+    int kchunk;           // K range of one workgroup (blockIdx.z), multiple of 32
     const float* bias;    // EPI_BIAS: per-m bias
     float* Pm;            // EPI_ADAMW: moments, same indexing as C
     float* Pv;
@@ -54,57 +64,53 @@ __device__ __forceinline__ f32x4 ov_ld_kc(const float* __restrict__ rowbase, int
     return v;
 }
 
+// operand with the OTHER index contiguous: four separate rows k .. k+3; `rows` (LDS or NULL) holds the
+// gathered row numbers of the whole K range, relative to krow0
 template <bool FULL>
 __device__ __forceinline__ f32x4 ov_ld_mc(const float* __restrict__ base, int64_t ld, int col, int k, int kend,
-                                          const int32_t* __restrict__ gather) {
-    f32x4 v;
+                                          const int32_t* rows, int krow0) {
     float t[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int kk = k + j;
         if (FULL || kk < kend) {
-            const int64_t r = gather ? (int64_t)gather[kk] : (int64_t)kk;
+            const int64_t r = rows ? (int64_t)rows[kk - krow0] : (int64_t)kk;
             t[j] = base[r * ld + col];
         } else {
             t[j] = 0.f;
         }
     }
+    f32x4 v;
     v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3];
     return v;
 }
 
-template <int MT, int NT, bool A_KC, bool B_KC, bool VEC, int EPI>
+template <int MT, int NT, int KW, int UK, bool A_KC, bool B_KC, bool VEC, int EPI>
 __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
+    extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
     const int lane = ov_lane();
     const int wave = ov_wave_id();
     const int i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * (64 * MT) + (wave >> 1) * (32 * MT);
-    const int n0 = blockIdx.x * (64 * NT) + (wave & 1) * (32 * NT);
-    const int kbeg = blockIdx.z * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
-    if (m0 >= p.M || n0 >= p.N) return;   // wave-uniform
+    const int m0 = KW == 1 ? blockIdx.y * (64 * MT) + (wave >> 1) * (32 * MT) : blockIdx.y * (32 * MT);
+    const int n0 = KW == 1 ? blockIdx.x * (64 * NT) + (wave & 1) * (32 * NT) : blockIdx.x * (32 * NT);
+    const int kb0 = blockIdx.z * p.kchunk;
+    const int kb1 = min(p.K, kb0 + p.kchunk);
+    int kbeg = kb0, kend = kb1;
+    if (KW == 4) {   // contiguous quarters of the block's range, multiples of 8
+        const int q = ((kb1 - kb0 + 4 * 8 - 1) / (4 * 8)) * 8;
+        kbeg = min(kb1, kb0 + wave * q);
+        kend = min(kb1, kbeg + q);
+    }
+    const bool tile_on = m0 < p.M && n0 < p.N;       // wave-uniform (block-uniform when KW == 4)
 
-    // per-lane operand bases (rows clamped: out-of-range rows are computed and never stored)
-    const float* abase[MT];
-    const float* bbase[NT];
-    int acol[MT], bcol[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = min(m0 + 32 * mt + i, p.M - 1);
-        acol[mt] = m;
-        abase[mt] = A_KC ? p.A + (int64_t)m * p.lda : p.A;
+    // gathered row numbers of the K range (B with n contiguous, k = batch row): one LDS copy per block
+    int32_t* rows = nullptr;
+    if (!B_KC && p.bgather) {
+        rows = reinterpret_cast<int32_t*>(ov_gemm_lds);
+        for (int t = threadIdx.x; t < kb1 - kb0; t += 256) rows[t] = p.bgather[kb0 + t];
+        __syncthreads();
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = min(n0 + 32 * nt + i, p.N - 1);
-        bcol[nt] = n;
-        if (B_KC) {
-            const int64_t r = p.bgather ? (int64_t)p.bgather[n] : (int64_t)n;
-            bbase[nt] = p.B + r * p.ldb;
-        } else {
-            bbase[nt] = p.B;
-        }
-    }
+    float* red = ov_gemm_lds;     // KW == 4 reduction area (never used together with `rows`)
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -114,54 +120,115 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    f32x4 a[MT], b[NT];
-    auto load_full = [&](int k0) {
-        const int k = k0 + 4 * h;
+    if (tile_on && kbeg < kend) {
+        // per-lane operand bases (rows clamped: out-of-range rows are computed and never stored)
+        const float* abase[MT];
+        const float* bbase[NT];
+        int acol[MT], bcol[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            a[mt] = A_KC ? ov_ld_kc<true, VEC>(abase[mt], k, kend) : ov_ld_mc<true>(abase[mt], p.lda, acol[mt], k, kend, nullptr);
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = min(m0 + 32 * mt + i, p.M - 1);
+            acol[mt] = m;
+            abase[mt] = A_KC ? p.A + (int64_t)m * p.lda : p.A;
+        }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            b[nt] = B_KC ? ov_ld_kc<true, VEC>(bbase[nt], k, kend) : ov_ld_mc<true>(bbase[nt], p.ldb, bcol[nt], k, kend, p.bgather);
-    };
-    auto load_tail = [&](int k0) {
-        const int k = k0 + 4 * h;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = min(n0 + 32 * nt + i, p.N - 1);
+            bcol[nt] = n;
+            if (B_KC) {
+                const int64_t r = p.bgather ? (int64_t)p.bgather[n] : (int64_t)n;
+                bbase[nt] = p.B + r * p.ldb;
+            } else {
+                bbase[nt] = p.B;
+            }
+        }
+        f32x4 a[2][UK][MT], b[2][UK][NT];
+        auto load_batch = [&](int buf, int k0) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            a[mt] = A_KC ? ov_ld_kc<false, VEC>(abase[mt], k, kend) : ov_ld_mc<false>(abase[mt], p.lda, acol[mt], k, kend, nullptr);
+            for (int u = 0; u < UK; ++u) {
+                const int k = k0 + 8 * u + 4 * h;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            b[nt] = B_KC ? ov_ld_kc<false, VEC>(bbase[nt], k, kend) : ov_ld_mc<false>(bbase[nt], p.ldb, bcol[nt], k, kend, p.bgather);
-    };
-    auto mfma_step = [&](const f32x4 (&aa)[MT], const f32x4 (&bb)[NT]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
+                    a[buf][u][mt] = A_KC ? ov_ld_kc<true, VEC>(abase[mt], k, kend)
+                                         : ov_ld_mc<true>(abase[mt], p.lda, acol[mt], k, kend, nullptr, 0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[mt][t], bb[nt][t], acc[mt][nt], 0, 0, 0);
-    };
-
-    const int nfull = (kend - kbeg) / 8;
-    int k0 = kbeg;
-    if (nfull > 0) {
-        load_full(k0);
-        for (int it = 0; it < nfull; ++it) {
-            f32x4 ca[MT], cb[NT];
+                    b[buf][u][nt] = B_KC ? ov_ld_kc<true, VEC>(bbase[nt], k, kend)
+                                         : ov_ld_mc<true>(bbase[nt], p.ldb, bcol[nt], k, kend, rows, kb0);
+            }
+        };
+        auto mfma_batch = [&](int buf) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) ca[mt] = a[mt];
+            for (int u = 0; u < UK; ++u)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) cb[nt] = b[nt];
-            k0 += 8;
-            if (it + 1 < nfull) load_full(k0);     // prefetch the next k-step under this one's MFMAs
-            mfma_step(ca, cb);
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u][mt][t], b[buf][u][nt][t], acc[mt][nt], 0, 0, 0);
+        };
+        const int nbatch = (kend - kbeg) / (8 * UK);
+        int k0 = kbeg;
+        if (nbatch > 0) {
+            load_batch(0, k0);
+            int it = 0;
+            for (; it + 2 <= nbatch; it += 2) {      // two batches per trip so that the buffers have static names
+                load_batch(1, k0 + 8 * UK);
+                mfma_batch(0);
+                if (it + 2 < nbatch) load_batch(0, k0 + 16 * UK);
+                mfma_batch(1);
+                k0 += 16 * UK;
+            }
+            if (it < nbatch) {
+                mfma_batch(0);
+                k0 += 8 * UK;
+            }
+        }
+        for (; k0 < kend; k0 += 8) {                  // remainder: single guarded k-steps
+            const int k = k0 + 4 * h;
+            f32x4 ta[MT], tb[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                ta[mt] = A_KC ? ov_ld_kc<false, VEC>(abase[mt], k, kend) : ov_ld_mc<false>(abase[mt], p.lda, acol[mt], k, kend, nullptr, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                tb[nt] = B_KC ? ov_ld_kc<false, VEC>(bbase[nt], k, kend) : ov_ld_mc<false>(bbase[nt], p.ldb, bcol[nt], k, kend, rows, kb0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[mt][t], tb[nt][t], acc[mt][nt], 0, 0, 0);
         }
     }
-    if (k0 < kend) {
-        load_tail(k0);
-        mfma_step(a, b);
+
+    if (KW == 4) {
+        // combine the four K-quarters: waves 2, 3 -> LDS -> waves 0, 1; wave 1 -> LDS -> wave 0
+        constexpr int TT = MT * NT;
+        auto put = [&](int slot) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((slot * TT + t) * 16 + r) * 64 + lane] = acc[t / NT][t % NT][r];
+        };
+        auto add = [&](int slot) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t / NT][t % NT][r] += red[((slot * TT + t) * 16 + r) * 64 + lane];
+        };
+        if (wave >= 2) put(wave - 2);
+        __syncthreads();
+        if (wave < 2) add(wave);
+        __syncthreads();
+        if (wave == 1) put(0);
+        __syncthreads();
+        if (wave != 0) return;
+        add(0);
     }
+    if (!tile_on) return;
 
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -169,20 +236,35 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = n0 + 32 * nt + i;
+            if (EPI == OV_EPI_ADAMW) {
+                // all parameter / moment loads of the tile first, then the arithmetic, then the stores
+                float w[16], mm[16], vv[16];
+                bool ok[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < p.M && n < p.N) {
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    ok[r] = m < p.M && n < p.N;
                     const int64_t idx = (int64_t)m * p.ldc + n;
-                    float val = acc[mt][nt][r];
-                    if (EPI == OV_EPI_STORE) {
-                        p.C[(int64_t)blockIdx.z * p.slab_stride + idx] = val;
-                    } else if (EPI == OV_EPI_BIAS) {
-                        p.C[idx] = val + p.bias[m];
-                    } else {
-                        float w = p.C[idx], mm = p.Pm[idx], vv = p.Pv[idx];
-                        ov_adamw(w, mm, vv, val, p.adam, false);
-                        p.C[idx] = w; p.Pm[idx] = mm; p.Pv[idx] = vv;
+                    w[r] = ok[r] ? p.C[idx] : 0.f;
+                    mm[r] = ok[r] ? p.Pm[idx] : 0.f;
+                    vv[r] = ok[r] ? p.Pv[idx] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ov_adamw(w[r], mm[r], vv[r], acc[mt][nt][r], p.adam, false);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int64_t idx = (int64_t)m * p.ldc + n;
+                    if (ok[r]) { p.C[idx] = w[r]; p.Pm[idx] = mm[r]; p.Pv[idx] = vv[r]; }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < p.M && n < p.N) {
+                        const int64_t idx = (int64_t)m * p.ldc + n;
+                        if (EPI == OV_EPI_STORE) p.C[(int64_t)blockIdx.z * p.slab_stride + idx] = acc[mt][nt][r];
+                        else p.C[idx] = acc[mt][nt][r] + p.bias[m];
                     }
                 }
             }

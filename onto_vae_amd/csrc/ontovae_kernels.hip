@@ -107,13 +107,14 @@ struct OvWs {
     int npart_max;
 };
 
-// split-K factor of the encoder forward GEMM (M = L, N = B, K = G): enough slabs to fill the chip
+// Encoder forward GEMM (M = L, N = B, K = G): wave tile 96 x (32 NT), four waves of a workgroup split
+// its K range, and enough workgroups along K to give every CU one (they each keep one wave per SIMD)
+static int ov_enc_nt(int B) { return B <= 32 ? 1 : (B <= 64 ? 2 : 4); }
 static int ov_enc_splitk(int L, int B, int G) {
-    const int tiles = ((L + 63) / 64) * ((B + 63) / 64);
-    int s = (768 + tiles - 1) / tiles;
+    const int tiles = ((L + 95) / 96) * ((B + 32 * ov_enc_nt(B) - 1) / (32 * ov_enc_nt(B)));
+    int s = (256 + tiles - 1) / tiles;
     const int smax = std::max(1, G / 256);
-    s = std::max(1, std::min(std::min(s, 64), smax));
-    return s;
+    return std::max(1, std::min(std::min(s, 128), smax));
 }
 
 static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs* ws) {
@@ -568,78 +569,130 @@ __global__ __launch_bounds__(256) void ov_sell_refresh_kernel(const float* __res
 // lanes that share a node, one store to LDS and one to the feature-major matrix in HBM.
 //   FWD: out = bias + sum w * panel[idx]      BWD: out = D (gene part, from HBM) + sum w * dpanel[idx]
 // -------------------------------------------------------------------------------------------------
+struct OvRec {          // chunk 0 of one lane of a slice
+    int node, info;
+    int id[8];
+    float w[8];
+    float bias;
+};
+
+template <bool BWD>
+__device__ __forceinline__ void ov_rec_load(OvRec& r, int sl, int lane, const int32_t* __restrict__ snode,
+                                            const int32_t* __restrict__ sinfo, const int32_t* __restrict__ chunk0,
+                                            const int32_t* __restrict__ sidx, const float* __restrict__ sw,
+                                            const float* __restrict__ sbias, int single) {
+    const int c0 = single ? sl : chunk0[sl];
+    const int base = c0 * 512 + lane;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r.id[e] = sidx[base + e * 64];
+        r.w[e] = sw[base + e * 64];
+    }
+    r.node = snode[sl * 64 + lane];
+    r.info = sinfo[sl * 64 + lane];
+    r.bias = BWD ? 0.f : sbias[sl * 64 + lane];
+}
+
 template <int BT, bool BWD>
 __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __restrict__ snode, const int32_t* __restrict__ sinfo,
                                                           const int32_t* __restrict__ chunk0, const int32_t* __restrict__ sidx,
                                                           const float* __restrict__ sw, const float* __restrict__ sbias,
-                                                          float* __restrict__ glob, int ldb, int z0, int z1, int single,
-                                                          const OvLevels lv) {
+                                                          float* __restrict__ glob, int ldb, int in0, int in1, int out0, int out1,
+                                                          int single, const OvLevels lv, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float ov_panel[];
     const int b0 = blockIdx.x * BT;
     const int lane = ov_lane();
     const int wave = ov_wave_id();
-    if (!BWD) {   // level 0 (z) comes from HBM
-        for (int p = z0 + threadIdx.x; p < z1; p += blockDim.x) {
-            float v[BT];
-            ov_ldv<BT>(glob + (int64_t)p * ldb + b0, v);
-            ov_stv<BT>(ov_panel + (int64_t)p * BT, v);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+
+    // this wave's slice sequence: (level pl, slice psl), advanced one slice ahead of the one being computed
+    int pl = 0, psl = lv.n > 0 ? lv.first[0] + wave : 0;
+    while (pl < lv.n && psl >= lv.first[pl] + lv.count[pl]) {
+        ++pl;
+        if (pl < lv.n) psl = lv.first[pl] + wave;
     }
-    for (int li = 0; li < lv.n; ++li) {
+    OvRec nxt;
+    if (pl < lv.n) ov_rec_load<BWD>(nxt, psl, lane, snode, sinfo, chunk0, sidx, sw, sbias, single);
+
+    // prologue: the rows the chain starts from, HBM -> LDS.  FWD: level 0 (z).  BWD: every panel row
+    // (the gene layer's contribution, written by ov_dec_bwd_gene_kernel).
+    for (int p = in0 + threadIdx.x; p < in1; p += 4096) {
+        float v[4][BT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p + u * 1024 < in1) ov_ldv<BT>(glob + (int64_t)(p + u * 1024) * ldb + b0, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p + u * 1024 < in1) ov_stv<BT>(ov_panel + (int64_t)(p + u * 1024) * BT, v[u]);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int li = 0; li < ((dbg & 2) ? 0 : lv.n); ++li) {
         const int s_end = lv.first[li] + lv.count[li];
         for (int sl = lv.first[li] + wave; sl < s_end; sl += 16) {
-            const int c0 = single ? sl : chunk0[sl];
-            const int R = single ? 1 : chunk0[sl + 1] - c0;
-            const int node = snode[sl * 64 + lane];
-            const int info = sinfo[sl * 64 + lane];
-            const int cnt = info & 0xFFFF;
-            const int lg = __builtin_amdgcn_readfirstlane((info >> 16) & 7);
-            const bool writer = (info >> 24) & 1;
-            float init[BT];
-#pragma unroll
-            for (int j = 0; j < BT; ++j) init[j] = 0.f;
-            if (writer) {
-                if (BWD) {
-                    ov_ldv<BT>(glob + (int64_t)node * ldb + b0, init);
-                } else {
-                    const float bv = sbias[sl * 64 + lane];
-#pragma unroll
-                    for (int j = 0; j < BT; ++j) init[j] = bv;
-                }
+            const OvRec cur = nxt;
+            psl += 16;
+            while (pl < lv.n && psl >= lv.first[pl] + lv.count[pl]) {
+                ++pl;
+                if (pl < lv.n) psl = lv.first[pl] + wave;
             }
+            if (pl < lv.n) ov_rec_load<BWD>(nxt, psl, lane, snode, sinfo, chunk0, sidx, sw, sbias, single);
+
+            const int cnt = cur.info & 0xFFFF;
+            const int lg = __builtin_amdgcn_readfirstlane((cur.info >> 16) & 7);
+            const bool writer = (cur.info >> 24) & 1;
             float acc[BT];
 #pragma unroll
             for (int j = 0; j < BT; ++j) acc[j] = 0.f;
-            for (int r = 0; r < R; ++r) {
-                const int base = (c0 + r) * 512 + lane;
-                int id[8];
-                float w[8], v[8][BT];
+            {
+                float v[8][BT];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    id[e] = sidx[base + e * 64];
-                    w[e] = sw[base + e * 64];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ov_ldv<BT>(ov_panel + (int64_t)id[e] * BT, v[e]);
-                const int rem = cnt - r * 8;
+                for (int e = 0; e < 8; ++e) ov_ldv<BT>(ov_panel + (int64_t)cur.id[e] * BT, v[e]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
 #pragma unroll
-                    for (int j = 0; j < BT; ++j) acc[j] += e < rem ? w[e] * v[e][j] : 0.f;   // padding never enters the sum
+                    for (int j = 0; j < BT; ++j) acc[j] += e < cnt ? cur.w[e] * v[e][j] : 0.f;   // padding never enters the sum
+            }
+            if (!single) {          // lanes with more than 8 entries: further chunks, loaded on demand
+                const int c0 = chunk0[sl], R = chunk0[sl + 1] - c0;
+                for (int r = 1; r < R; ++r) {
+                    const int base = (c0 + r) * 512 + lane;
+                    const int rem = cnt - r * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float v0[BT];
+                        const float w0 = sw[base + e * 64];
+                        ov_ldv<BT>(ov_panel + (int64_t)sidx[base + e * 64] * BT, v0);
+#pragma unroll
+                        for (int j = 0; j < BT; ++j) acc[j] += e < rem ? w0 * v0[j] : 0.f;
+                    }
+                }
             }
             ov_group_sum_rt<BT>(acc, lg);
             if (writer) {
+                if (BWD) {
+                    float g0[BT];
+                    ov_ldv<BT>(ov_panel + (int64_t)cur.node * BT, g0);
 #pragma unroll
-                for (int j = 0; j < BT; ++j) acc[j] += init[j];
-                ov_stv<BT>(ov_panel + (int64_t)node * BT, acc);
-                ov_stv<BT>(glob + (int64_t)node * ldb + b0, acc);
+                    for (int j = 0; j < BT; ++j) acc[j] += g0[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < BT; ++j) acc[j] += cur.bias;
+                }
+                ov_stv<BT>(ov_panel + (int64_t)cur.node * BT, acc);
             }
         }
-        // LDS writes must land before the next level reads them; the HBM stores need no wait here
+        // LDS writes must land before the next level reads them (no HBM traffic inside the chain)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+    }
+
+    // epilogue: results LDS -> HBM (feature-major), for the gene layer and the weight gradient
+    if (!(dbg & 1))
+    for (int p = out0 + threadIdx.x; p < out1; p += 1024) {
+        float v[BT];
+        ov_ldv<BT>(ov_panel + (int64_t)p * BT, v);
+        ov_stv<BT>(glob + (int64_t)p * ldb + b0, v);
     }
 }
 
@@ -1080,11 +1133,24 @@ static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
     return ONTOVAE_OK;
 }
 
-template <int MT, int NT, bool A_KC, bool B_KC, int EPI>
+template <int MT, int NT, int KW, int UK, bool A_KC, bool B_KC, int EPI>
 static int ov_launch_gemm(const OvGemm& g, int S, bool vec, hipStream_t st) {
-    dim3 grid((g.N + 64 * NT - 1) / (64 * NT), (g.M + 64 * MT - 1) / (64 * MT), S);
-    if (vec) hipLaunchKernelGGL((ov_gemm_kernel<MT, NT, A_KC, B_KC, true, EPI>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((ov_gemm_kernel<MT, NT, A_KC, B_KC, false, EPI>), grid, dim3(256), 0, st, g);
+    const int bm = KW == 1 ? 64 * MT : 32 * MT, bn = KW == 1 ? 64 * NT : 32 * NT;
+    dim3 grid((g.N + bn - 1) / bn, (g.M + bm - 1) / bm, S);
+    size_t lds = 0;
+    if (KW == 4) lds = (size_t)2 * MT * NT * 16 * 64 * sizeof(float);
+    if (!B_KC && g.bgather) lds = std::max(lds, (size_t)std::min(g.K, g.kchunk) * sizeof(int32_t));
+    if (KW == 4 && !B_KC && g.bgather) { ontovae_set_error("gemm: in-block split-K cannot be combined with a gathered K"); return ONTOVAE_EINVAL; }
+    if (lds > 160 * 1024) { ontovae_set_error("gemm: %zu bytes of LDS needed", lds); return ONTOVAE_EINVAL; }
+#define OV_GL(V)                                                                                                  \
+    do {                                                                                                          \
+        auto kern = ov_gemm_kernel<MT, NT, KW, UK, A_KC, B_KC, V, EPI>;                                            \
+        if (lds > 48 * 1024)                                                                                      \
+            OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);                                                    \
+    } while (0)
+    if (vec) OV_GL(true); else OV_GL(false);
+#undef OV_GL
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
@@ -1106,7 +1172,7 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     const ontovae_dims_t& d = s.c->dims;
     const int S = ov_enc_splitk(d.L, s.B, d.G);
     int kchunk = (d.G + S - 1) / S;
-    kchunk = (kchunk + 7) / 8 * 8;
+    kchunk = (kchunk + 31) / 32 * 32;
     const int Seff = (d.G + kchunk - 1) / kchunk;
     OvGemm g{};
     g.M = d.L; g.N = s.B; g.K = d.G;
@@ -1116,7 +1182,10 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     const bool vec = (d.G % 4 == 0) && (s.xld % 4 == 0) && ov_al16(g.A) && ov_al16(g.B);
     *S_out = Seff;
     OvProfScope prof(ONTOVAE_PHASE_ENC_GEMM, s.st);
-    return ov_launch_gemm<1, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
+    const int nt = ov_enc_nt(s.B);
+    if (nt == 1) return ov_launch_gemm<3, 1, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
+    if (nt == 2) return ov_launch_gemm<3, 2, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
+    return ov_launch_gemm<3, 4, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
 }
 
 static int ov_bn_fwd(OvStep& s, int S, int mode, int Bglobal, float* stats, uint64_t rng_off) {
@@ -1139,11 +1208,11 @@ static int ov_heads_fwd(OvStep& s) {
     g.M = 2 * d.L; g.N = s.B; g.K = d.L;
     g.A = c->P + c->lay.Wh; g.lda = d.L;
     g.B = s.ws.a; g.ldb = s.ldb; g.bgather = nullptr;
-    g.C = s.ws.mulv; g.ldc = s.ldb; g.kchunk = (d.L + 7) / 8 * 8;
+    g.C = s.ws.mulv; g.ldc = s.ldb; g.kchunk = (d.L + 31) / 32 * 32;
     g.bias = c->P + c->lay.bh;
     const bool vec = (d.L % 4 == 0) && ov_al16(g.A);
     OvProfScope prof(ONTOVAE_PHASE_HEADS, s.st);
-    return ov_launch_gemm<1, 1, true, false, OV_EPI_BIAS>(g, 1, vec, s.st);
+    return ov_launch_gemm<1, 1, 4, 4, true, false, OV_EPI_BIAS>(g, 1, vec, s.st);
 }
 
 static int ov_reparam(OvStep& s, const float* eps, int train, uint64_t rng_off, uint32_t eps_stream, int write_kl, int* nkl) {
@@ -1237,7 +1306,7 @@ static int ov_dec_forward_terms(OvStep& s) {
 #define OV_TF(BT)                                                                                                     \
     if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false>, lds))) return rc;                                             \
     hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false>), dim3(s.ldb / BT), dim3(1024), lds, s.st, f.node, f.info, f.chunk0, \
-                       f.idx, f.w, f.bias, s.ws.act, s.ldb, d.C - d.L, d.C, f.all_single_chunk, lv)
+                       f.idx, f.w, f.bias, s.ws.act, s.ldb, d.C - d.L, d.C, 0, d.C - d.L, f.all_single_chunk, lv, (int)(c->flags >> 8))
     if (bt == 4) { OV_TF(4); } else if (bt == 2) { OV_TF(2); } else { OV_TF(1); }
 #undef OV_TF
     OV_LAUNCH_CHECK();
@@ -1313,7 +1382,7 @@ static int ov_dec_backward(OvStep& s) {
 #define OV_TB(BT)                                                                                                     \
     if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true>, lds))) return rc;                                              \
     hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true>), dim3(s.ldb / BT), dim3(1024), lds, s.st, sb.node, sb.info, sb.chunk0, \
-                       sb.idx, sb.w, (const float*)nullptr, s.ws.d, s.ldb, 0, 0, sb.all_single_chunk, lv)
+                       sb.idx, sb.w, (const float*)nullptr, s.ws.d, s.ldb, 0, d.C, 0, d.C, sb.all_single_chunk, lv, (int)(c->flags >> 8))
     if (bt == 4) { OV_TB(4); } else if (bt == 2) { OV_TB(2); } else { OV_TB(1); }
 #undef OV_TB
     OV_LAUNCH_CHECK();
@@ -1495,9 +1564,9 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         g.M = d.L; g.N = s.B; g.K = 2 * d.L;
         g.A = c->P + lay.Wh; g.lda = d.L;          // A(m=l, k=j) = Wh[j*L + l]
         g.B = s.ws.dmulv; g.ldb = s.ldb;
-        g.C = s.ws.da; g.ldc = s.ldb; g.kchunk = (2 * d.L + 7) / 8 * 8;
+        g.C = s.ws.da; g.ldc = s.ldb; g.kchunk = (2 * d.L + 31) / 32 * 32;
         OvProfScope prof(ONTOVAE_PHASE_DA_GEMM, s.st);
-        if ((rc = ov_launch_gemm<1, 1, false, false, OV_EPI_STORE>(g, 1, false, s.st))) return rc;
+        if ((rc = ov_launch_gemm<1, 1, 4, 4, false, false, OV_EPI_STORE>(g, 1, false, s.st))) return rc;
     }
     // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv)
     {
@@ -1505,15 +1574,15 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         g.M = 2 * d.L; g.N = d.L; g.K = s.B;
         g.A = s.ws.dmulv; g.lda = s.ldb;
         g.B = s.ws.a; g.ldb = s.ldb;
-        g.ldc = d.L; g.kchunk = (s.B + 7) / 8 * 8;
+        g.ldc = d.L; g.kchunk = (s.B + 31) / 32 * 32;
         g.adam = adam;
         OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
         if (apply) {
             g.C = c->P + lay.Wh; g.Pm = c->M + lay.Wh; g.Pv = c->V + lay.Wh;
-            if ((rc = ov_launch_gemm<1, 1, true, true, OV_EPI_ADAMW>(g, 1, true, s.st))) return rc;
+            if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_ADAMW>(g, 1, true, s.st))) return rc;
         } else {
             g.C = c->Gr + lay.Wh;
-            if ((rc = ov_launch_gemm<1, 1, true, true, OV_EPI_STORE>(g, 1, true, s.st))) return rc;
+            if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_STORE>(g, 1, true, s.st))) return rc;
         }
         hipLaunchKernelGGL(ov_rowsum_adamw_kernel, dim3((2 * d.L + 3) / 4), dim3(256), 0, s.st, s.ws.dmulv, 2 * d.L, s.ldb,
                            c->P + lay.bh, c->M ? c->M + lay.bh : nullptr, c->V ? c->V + lay.bh : nullptr,
@@ -1543,15 +1612,15 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     g.M = d.L; g.N = d.G; g.K = s.B;
     g.A = s.ws.dh; g.lda = s.ldb;
     g.B = s.x; g.ldb = s.xld; g.bgather = s.xidx;     // B(k=b, n=g) = X[row(b) * G + g]
-    g.ldc = d.G; g.kchunk = (s.B + 7) / 8 * 8;
+    g.ldc = d.G; g.kchunk = (s.B + 31) / 32 * 32;
     g.adam = ov_adam_from(opt);
     OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
     if (apply) {
         g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
-        return ov_launch_gemm<1, 1, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
+        return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
     }
     g.C = c->Gr + c->lay.W0;
-    return ov_launch_gemm<1, 1, true, false, OV_EPI_STORE>(g, 1, true, s.st);
+    return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_STORE>(g, 1, true, s.st);
 }
 
 extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
