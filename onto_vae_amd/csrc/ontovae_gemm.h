@@ -29,7 +29,9 @@
 
 #include "ontovae_device.h"
 
-enum { OV_EPI_STORE = 0, OV_EPI_BIAS = 1, OV_EPI_ADAMW = 2 };
+// OV_EPI_ADAMW_T: AdamW with the tile transposed through LDS first, so that the parameter / moment traffic
+// is 16 B per lane along n (512-B runs per row for a 128-wide wave tile) instead of 128-B pieces
+enum { OV_EPI_STORE = 0, OV_EPI_BIAS = 1, OV_EPI_ADAMW = 2, OV_EPI_ADAMW_T = 3 };
 
 struct OvGemm {
     int M, N, K;
@@ -46,6 +48,7 @@ struct OvGemm {
     float* Pm;            // EPI_ADAMW: moments, same indexing as C
     float* Pv;
     OvAdam adam;
+    int dbg;              // measurement only: 1 = skip the main loop, 2 = skip the epilogue
 };
 
 template <bool FULL, bool VEC>
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    if (tile_on && kbeg < kend) {
+    if (tile_on && kbeg < kend && !(p.dbg & 1)) {
         // per-lane operand bases (rows clamped: out-of-range rows are computed and never stored)
         const float* abase[MT];
         const float* bbase[NT];
@@ -230,6 +233,67 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
     }
     if (!tile_on) return;
 
+    if (p.dbg & 2) {
+        float sink = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sink += acc[mt][nt][r];
+        if (sink == 1.2345e-30f) p.C[0] = sink;
+        return;
+    }
+    if (EPI == OV_EPI_ADAMW_T) {
+        constexpr int TW = 32 * NT, LDW = TW + 4, TR = 32 * MT, C4 = TW / 4, RPI = 64 / C4;
+        // wave-private LDS tile behind the (optional) gathered-row table
+        const int rows_floats = (!B_KC && p.bgather) ? ((kb1 - kb0 + 3) / 4 * 4) : 0;
+        float* tile = ov_gemm_lds + rows_floats + wave * (TR * LDW);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h) * LDW + 32 * nt + i] = acc[mt][nt][r];
+        const int c4 = lane % C4, rr = lane / C4;
+        const int n = n0 + 4 * c4;
+#pragma unroll 1
+        for (int row0 = 0; row0 < TR; row0 += 4 * RPI) {
+            f32x4 w[4], mm[4], vv[4], g[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = row0 + u * RPI + rr;
+                const int m = m0 + row;
+                ok[u] = row < TR && m < p.M && n < p.N;
+                const int64_t idx = (int64_t)m * p.ldc + n;
+                if (ok[u]) {
+                    w[u] = *reinterpret_cast<const f32x4*>(p.C + idx);
+                    mm[u] = *reinterpret_cast<const f32x4*>(p.Pm + idx);
+                    vv[u] = *reinterpret_cast<const f32x4*>(p.Pv + idx);
+                    g[u] = *reinterpret_cast<const f32x4*>(tile + row * LDW + 4 * c4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ok[u]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float ww = w[u][e], m1 = mm[u][e], v1 = vv[u][e];
+                        ov_adamw(ww, m1, v1, g[u][e], p.adam, false);
+                        w[u][e] = ww; mm[u][e] = m1; vv[u][e] = v1;
+                    }
+                    const int64_t idx = (int64_t)(m0 + row0 + u * RPI + rr) * p.ldc + n;
+                    *reinterpret_cast<f32x4*>(p.C + idx) = w[u];
+                    *reinterpret_cast<f32x4*>(p.Pm + idx) = mm[u];
+                    *reinterpret_cast<f32x4*>(p.Pv + idx) = vv[u];
+                }
+            }
+        }
+        return;
+    }
+
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -269,6 +333,185 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
                 }
             }
         }
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// LDS-staged variant for the two large products (encoder forward, dW0).
+//
+// Fragment-shaped global loads touch 32 cache lines per wave instruction and every line four times;
+// at the sizes of the first encoder layer that load-path work, not the MFMA pipe, set the pace.  Here
+// a workgroup stages a (96 WM) x 32 tile of A and a 32 x (32 WN) tile of B per K-step of 32 through
+// LDS with whole-line 16-B-per-lane loads (each line fetched once per workgroup, shared by its four
+// waves), prefetches the next stage into registers under the current stage's MFMAs, and reads MFMA
+// fragments with ds_read_b128 (k-contiguous operands, row stride 36 floats: conflict-free) or
+// ds_read_b32 (n-contiguous B).  Wave grid WM x WN (WM * WN = 4), wave tile 96 x 32.
+//   encoder forward: WM = 1, WN = 4, B_KC (x rows, gathered), split-K slabs over blockIdx.z
+//   dW0            : WM = 4, WN = 1, B n-contiguous (x[row(b), g]), K = batch, AdamW epilogue
+// Requires 16-B aligned rows (lda, ldb multiples of 4); the host falls back to ov_gemm_kernel otherwise.
+// -------------------------------------------------------------------------------------------------
+template <int WM, int WN, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
+    constexpr int MT = 3, BK = 32, LDK = BK + 4;
+    constexpr int RA = 32 * MT * WM;              // A rows per workgroup
+    constexpr int RB = 32 * WN;                   // B columns (n) per workgroup
+    constexpr int UA = RA * 8 / 256;              // float4 units per thread, A tile
+    constexpr int UB = B_KC ? RB * 8 / 256 : (BK * RB / 4 + 255) / 256;
+    constexpr int LDN = RB + 4;
+    extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
+    float* As = ov_gemm_lds;                      // [RA][LDK]
+    float* Bs = ov_gemm_lds + RA * LDK;           // B_KC: [RB][LDK]   else [BK][LDN]
+    int32_t* rows = reinterpret_cast<int32_t*>(Bs + (B_KC ? RB * LDK : BK * LDN));   // gathered rows of the K range (!B_KC)
+    const int tid = threadIdx.x;
+    const int lane = ov_lane();
+    const int wave = ov_wave_id();
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = WM == 4 ? wave : 0, wn = WN == 4 ? wave : 0;
+    const int m0 = blockIdx.y * RA, n0 = blockIdx.x * RB;
+    const int kb0 = blockIdx.z * p.kchunk;
+    const int kb1 = min(p.K, kb0 + p.kchunk);
+    if (!B_KC) {
+        for (int t = tid; t < kb1 - kb0; t += 256) rows[t] = p.bgather ? p.bgather[kb0 + t] : kb0 + t;
+        __syncthreads();
+    }
+    // staging assignments (fixed per thread over the whole K loop)
+    const float* asrc[UA];
+    int adst[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int unit = tid + 256 * u, r = unit >> 3, kq = unit & 7;
+        asrc[u] = p.A + (int64_t)min(m0 + r, p.M - 1) * p.lda + 4 * kq;
+        adst[u] = r * LDK + 4 * kq;
+    }
+    const float* bsrc[UB];
+    int bdst[UB], bk[UB];
+    bool bok[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        const int unit = tid + 256 * u;
+        if (B_KC) {
+            const int r = unit >> 3, kq = unit & 7;
+            const int n = min(n0 + r, p.N - 1);
+            const int64_t row = p.bgather ? (int64_t)p.bgather[n] : (int64_t)n;
+            bsrc[u] = p.B + row * p.ldb + 4 * kq;
+            bdst[u] = r * LDK + 4 * kq;
+            bk[u] = 0;
+            bok[u] = true;
+        } else {
+            constexpr int Q = RB / 4;                         // float4 per k row
+            const int k = unit / Q, q = unit % Q;
+            bsrc[u] = p.B + n0 + 4 * q;
+            bdst[u] = k * LDN + 4 * q;
+            bk[u] = k;
+            bok[u] = k < BK && n0 + 4 * q < p.N;
+        }
+    }
+    f32x4 ra[UA], rb[UB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int k = k0 + 4 * ((tid + 256 * u) & 7);
+            if (k + 3 < kb1) ra[u] = *reinterpret_cast<const f32x4*>(asrc[u] + k0);
+            else {
+                ra[u].x = k < kb1 ? asrc[u][k0] : 0.f;
+                ra[u].y = k + 1 < kb1 ? asrc[u][k0 + 1] : 0.f;
+                ra[u].z = k + 2 < kb1 ? asrc[u][k0 + 2] : 0.f;
+                ra[u].w = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (B_KC) {
+                const int k = k0 + 4 * ((tid + 256 * u) & 7);
+                if (k + 3 < kb1) rb[u] = *reinterpret_cast<const f32x4*>(bsrc[u] + k0);
+                else {
+                    rb[u].x = k < kb1 ? bsrc[u][k0] : 0.f;
+                    rb[u].y = k + 1 < kb1 ? bsrc[u][k0 + 1] : 0.f;
+                    rb[u].z = k + 2 < kb1 ? bsrc[u][k0 + 2] : 0.f;
+                    rb[u].w = 0.f;
+                }
+            } else {
+                const int k = k0 + bk[u];
+                if (bok[u] && k < kb1) rb[u] = *reinterpret_cast<const f32x4*>(bsrc[u] + (int64_t)rows[k - kb0] * p.ldb);
+                else rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int u = 0; u < UA; ++u) *reinterpret_cast<f32x4*>(As + adst[u]) = ra[u];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (B_KC || bk[u] < BK) *reinterpret_cast<f32x4*>(Bs + bdst[u]) = rb[u];
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    if (kb0 < kb1) gload(kb0);
+    for (int k0 = kb0; k0 < kb1; k0 += BK) {
+        __syncthreads();                  // everybody is done reading the previous stage
+        lstore();
+        __syncthreads();
+        if (k0 + BK < kb1) gload(k0 + BK);      // next stage in flight under this stage's MFMAs
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            f32x4 fa[MT], fb;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                fa[mt] = *reinterpret_cast<const f32x4*>(As + (wm * 32 * MT + 32 * mt + i) * LDK + 8 * s + 4 * h);
+            if (B_KC) {
+                fb = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + i) * LDK + 8 * s + 4 * h);
+            } else {
+                fb.x = Bs[(8 * s + 4 * h + 0) * LDN + wn * 32 + i];
+                fb.y = Bs[(8 * s + 4 * h + 1) * LDN + wn * 32 + i];
+                fb.z = Bs[(8 * s + 4 * h + 2) * LDN + wn * 32 + i];
+                fb.w = Bs[(8 * s + 4 * h + 3) * LDN + wn * 32 + i];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][t], fb[t], acc[mt], 0, 0, 0);
+        }
+    }
+
+    // epilogue; C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int n = n0 + wn * 32 + i;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int mb = m0 + wm * 32 * MT + 32 * mt;
+        if (EPI == OV_EPI_ADAMW) {
+            float w[16], mm[16], vv[16];
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                ok[r] = m < p.M && n < p.N;
+                const int64_t idx = (int64_t)m * p.ldc + n;
+                w[r] = ok[r] ? p.C[idx] : 0.f;
+                mm[r] = ok[r] ? p.Pm[idx] : 0.f;
+                vv[r] = ok[r] ? p.Pv[idx] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ov_adamw(w[r], mm[r], vv[r], acc[mt][r], p.adam, false);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t idx = (int64_t)m * p.ldc + n;
+                if (ok[r]) { p.C[idx] = w[r]; p.Pm[idx] = mm[r]; p.Pv[idx] = vv[r]; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M && n < p.N) p.C[(int64_t)blockIdx.z * p.slab_stride + (int64_t)m * p.ldc + n] = acc[mt][r];
+            }
+        }
+    }
 }
 
 #endif

@@ -173,24 +173,50 @@ __global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict_
                                                        float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                        float* __restrict__ stats, int L, int B, int Bglobal, int ldb,
                                                        int mode, float drop, uint64_t seed, uint64_t rng_off) {
-    const int l = blockIdx.x * 4 + ov_wave_id();
-    if (l >= L) return;
+    // one workgroup per feature: the four waves share the split-K combine (each sums a quarter of the
+    // slabs, 16 B per lane), wave 0 then owns the row
+    __shared__ __attribute__((aligned(16))) float part[4][256];
+    const int l = blockIdx.x;
     const int lane = ov_lane();
+    const int wave = ov_wave_id();
     float* xr = xhat + (int64_t)l * ldb;
     float* ar = a + (int64_t)l * ldb;
     float mean, var;
     if (mode != 3) {
         const float bias = b0[l];
         float s = 0.f;
-        for (int b = lane; b < ldb; b += 64) {
-            float h = 0.f;
-            if (b < B) {
-                for (int z = 0; z < S; ++z) h += slab[(int64_t)z * slab_stride + (int64_t)l * ldb + b];
-                h += bias;
-                s += h;
+        for (int c0 = 0; c0 < ldb; c0 += 256) {
+            const int b = c0 + lane * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (b < ldb) {
+                const float* src = slab + (int64_t)l * ldb + b;
+                int z = wave;
+                for (; z + 12 < S; z += 16) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (int64_t)z * slab_stride);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 4) * slab_stride);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 8) * slab_stride);
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 12) * slab_stride);
+                    acc += (v0 + v1) + (v2 + v3);
+                }
+                for (; z < S; z += 4) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)z * slab_stride);
             }
-            xr[b] = h;
+            *reinterpret_cast<f32x4*>(&part[wave][lane * 4]) = acc;
+            __syncthreads();
+            if (wave == 0 && b < ldb) {
+                f32x4 h4 = (*reinterpret_cast<const f32x4*>(&part[0][lane * 4]) + *reinterpret_cast<const f32x4*>(&part[1][lane * 4])) +
+                           (*reinterpret_cast<const f32x4*>(&part[2][lane * 4]) + *reinterpret_cast<const f32x4*>(&part[3][lane * 4]));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float h = b + j < B ? h4[j] + bias : 0.f;     // slab columns >= B were never written
+                    h4[j] = h;
+                    s += h;
+                }
+                *reinterpret_cast<f32x4*>(xr + b) = h4;
+            }
+            __syncthreads();
         }
+        if (wave != 0) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row just stored is re-read by other lanes below
         if (mode == 0) {
             mean = rmean[l];
             var = rvar[l];
@@ -212,6 +238,7 @@ __global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict_
             var = q / (float)B;
         }
     } else {
+        if (wave != 0) return;
         mean = stats[l];
         var = stats[L + l];
     }
@@ -1140,6 +1167,11 @@ static int ov_launch_gemm(const OvGemm& g, int S, bool vec, hipStream_t st) {
     size_t lds = 0;
     if (KW == 4) lds = (size_t)2 * MT * NT * 16 * 64 * sizeof(float);
     if (!B_KC && g.bgather) lds = std::max(lds, (size_t)std::min(g.K, g.kchunk) * sizeof(int32_t));
+    if (EPI == OV_EPI_ADAMW_T) {
+        if (KW != 1) { ontovae_set_error("gemm: the transposed AdamW epilogue needs KW == 1"); return ONTOVAE_EINVAL; }
+        const size_t rows_floats = (!B_KC && g.bgather) ? (size_t)((std::min(g.K, g.kchunk) + 3) / 4 * 4) : 0;
+        lds = (rows_floats + (size_t)4 * (32 * MT) * (32 * NT + 4)) * sizeof(float);
+    }
     if (KW == 4 && !B_KC && g.bgather) { ontovae_set_error("gemm: in-block split-K cannot be combined with a gathered K"); return ONTOVAE_EINVAL; }
     if (lds > 160 * 1024) { ontovae_set_error("gemm: %zu bytes of LDS needed", lds); return ONTOVAE_EINVAL; }
 #define OV_GL(V)                                                                                                  \
@@ -1151,6 +1183,21 @@ static int ov_launch_gemm(const OvGemm& g, int S, bool vec, hipStream_t st) {
     } while (0)
     if (vec) OV_GL(true); else OV_GL(false);
 #undef OV_GL
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+template <int WM, int WN, bool B_KC, int EPI>
+static int ov_launch_gemm_lds(const OvGemm& g, int S, hipStream_t st) {
+    constexpr int RA = 96 * WM, RB = 32 * WN;
+    dim3 grid((g.N + RB - 1) / RB, (g.M + RA - 1) / RA, S);
+    size_t lds = (size_t)RA * 36 * sizeof(float) + (B_KC ? (size_t)RB * 36 : (size_t)32 * (RB + 4)) * sizeof(float);
+    if (!B_KC) lds += (size_t)std::min(g.K, g.kchunk) * sizeof(int32_t);
+    if (lds > 160 * 1024) { ontovae_set_error("gemm_lds: %zu bytes of LDS needed", lds); return ONTOVAE_EINVAL; }
+    auto kern = ov_gemm_lds_kernel<WM, WN, B_KC, EPI>;
+    if (lds > 48 * 1024)
+        OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
@@ -1181,10 +1228,13 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     g.C = s.ws.slab; g.ldc = s.ldb; g.slab_stride = (int64_t)d.L * s.ldb; g.kchunk = kchunk;
     const bool vec = (d.G % 4 == 0) && (s.xld % 4 == 0) && ov_al16(g.A) && ov_al16(g.B);
     *S_out = Seff;
+    g.dbg = (s.c->flags >> 18) & 3;
     OvProfScope prof(ONTOVAE_PHASE_ENC_GEMM, s.st);
     const int nt = ov_enc_nt(s.B);
+    if (vec && nt == 4 && !((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds<1, 4, true, OV_EPI_STORE>(g, Seff, s.st);
     if (nt == 1) return ov_launch_gemm<3, 1, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
     if (nt == 2) return ov_launch_gemm<3, 2, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
+    if ((s.c->flags >> 14) & 1) return ov_launch_gemm<3, 4, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
     return ov_launch_gemm<3, 4, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
 }
 
@@ -1192,7 +1242,7 @@ static int ov_bn_fwd(OvStep& s, int S, int mode, int Bglobal, float* stats, uint
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     OvProfScope prof(ONTOVAE_PHASE_BN_FWD, s.st);
-    hipLaunchKernelGGL(ov_bn_fwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb,
+    hipLaunchKernelGGL(ov_bn_fwd_kernel, dim3(d.L), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb,
                        c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, c->bn_nbt,
                        s.ws.xhat, s.ws.a, s.ws.bn_mean, s.ws.bn_invstd, stats, d.L, s.B, Bglobal, s.ldb, mode, c->drop, c->seed,
                        rng_off);
@@ -1614,12 +1664,20 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     g.B = s.x; g.ldb = s.xld; g.bgather = s.xidx;     // B(k=b, n=g) = X[row(b) * G + g]
     g.ldc = d.G; g.kchunk = (s.B + 31) / 32 * 32;
     g.adam = ov_adam_from(opt);
+    g.dbg = (c->flags >> 16) & 3;
     OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
     if (apply) {
         g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
-        return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
+        const int var = (c->flags >> 12) & 3;
+        const bool al = (d.G % 4 == 0) && ov_al16(g.C) && ov_al16(g.Pm) && ov_al16(g.Pv);
+        if (al && ov_al16(g.B) && ((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_ADAMW>(g, 1, s.st);
+        if (!al || var == 1) return ov_launch_gemm<1, 1, 1, 4, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
+        if (var == 2) return ov_launch_gemm<1, 2, 1, 2, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
+        if (var == 3) return ov_launch_gemm<1, 4, 1, 1, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
+        return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
     }
     g.C = c->Gr + c->lay.W0;
+    if ((d.G % 4 == 0) && ov_al16(g.B) && ((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_STORE>(g, 1, s.st);
     return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_STORE>(g, 1, true, s.st);
 }
 
