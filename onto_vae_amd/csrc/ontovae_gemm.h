@@ -123,6 +123,28 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // Fused AdamW (KW == 1): the tile's parameters and moments are requested BEFORE the K loop, so the
+    // optimizer's read traffic (the dominant HBM stream of dW0) runs under the MFMAs instead of after them.
+    constexpr bool PREF = (EPI == OV_EPI_ADAMW) && (KW == 1);
+    float pw[PREF ? MT : 1][PREF ? NT : 1][16], pm[PREF ? MT : 1][PREF ? NT : 1][16], pv[PREF ? MT : 1][PREF ? NT : 1][16];
+    if (PREF && tile_on) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + 32 * nt + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bool ok = m < p.M && n < p.N;
+                    const int64_t idx = (int64_t)m * p.ldc + n;
+                    pw[mt][nt][r] = ok ? p.C[idx] : 0.f;
+                    pm[mt][nt][r] = ok ? p.Pm[idx] : 0.f;
+                    pv[mt][nt][r] = ok ? p.Pv[idx] : 0.f;
+                }
+            }
+    }
+
     if (tile_on && kbeg < kend && !(p.dbg & 1)) {
         // per-lane operand bases (rows clamped: out-of-range rows are computed and never stored)
         const float* abase[MT];
@@ -147,6 +169,16 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
         }
         f32x4 a[2][UK][MT], b[2][UK][NT];
         auto load_batch = [&](int buf, int k0) {
+            if (p.dbg & 4) {      // measurement only: no global loads, MFMA pace alone
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[buf][u][mt] = f32x4{(float)k0, 1.f, (float)lane, 2.f};
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b[buf][u][nt] = f32x4{1.f, (float)k0, 3.f, (float)lane};
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
                 const int k = k0 + 8 * u + 4 * h;
@@ -309,9 +341,13 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
                     const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
                     ok[r] = m < p.M && n < p.N;
                     const int64_t idx = (int64_t)m * p.ldc + n;
-                    w[r] = ok[r] ? p.C[idx] : 0.f;
-                    mm[r] = ok[r] ? p.Pm[idx] : 0.f;
-                    vv[r] = ok[r] ? p.Pv[idx] : 0.f;
+                    if (PREF) {
+                        w[r] = pw[mt][nt][r]; mm[r] = pm[mt][nt][r]; vv[r] = pv[mt][nt][r];
+                    } else {
+                        w[r] = ok[r] ? p.C[idx] : 0.f;
+                        mm[r] = ok[r] ? p.Pm[idx] : 0.f;
+                        vv[r] = ok[r] ? p.Pv[idx] : 0.f;
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ov_adamw(w[r], mm[r], vv[r], acc[mt][nt][r], p.adam, false);
@@ -509,6 +545,115 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < p.M && n < p.N) p.C[(int64_t)blockIdx.z * p.slab_stride + (int64_t)m * p.ldc + n] = acc[mt][r];
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// dW0 = dh x (+ AdamW) for batches of at most 128 rows: the weight-gradient of the first encoder layer
+// (gradient of modules.py:46, optimizer step of vae_model.py:172).
+//
+// The product is a stream over W0 / exp_avg / exp_avg_sq (3 x 4 LG bytes in, 3 x 4 LG out) with only
+// K = batch <= 128 of arithmetic depth per element, so the kernel is organised around that stream:
+//   * a wave owns 32 genes (columns of W0) and keeps its whole x fragment, x[row(b), g0 .. g0+31] for all
+//     b, in 64 registers: x is read once per wave, not once per k-step;
+//   * a workgroup owns up to 128 rows of W0 (4 tiles of 32) and holds those rows of dh in LDS
+//     (row stride 132 floats: conflict-free ds_read_b128 fragments);
+//   * per 32x32 tile the parameter / moment loads are issued first, the 64 MFMAs run under them, then
+//     AdamW and the stores; the second wave of the SIMD is in a different phase, which is what overlaps
+//     the HBM stream with the matrix pipe.
+// Workgroups that share a gene range are given ids congruent mod 8, i.e. the same XCD, so the x tile is
+// fetched into one L2 only.
+// -------------------------------------------------------------------------------------------------
+template <int NW, int EPI>
+__global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njobs) {
+    constexpr int LT = 4, RA = 32 * LT, KMAX = 128, LDA = KMAX + 4;
+    extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
+    float* As = ov_gemm_lds;                                             // [RA][LDA]
+    int32_t* rows = reinterpret_cast<int32_t*>(ov_gemm_lds + RA * LDA);  // [KMAX], -1 beyond K
+    const int tid = threadIdx.x;
+    const int lane = ov_lane();
+    const int wave = ov_wave_id();
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const int job = (b >> 3) % njobs;
+    const int gx = (b / (8 * njobs)) * 8 + (b & 7);
+    const int m0 = job * RA;
+    const int n0 = (gx * NW + wave) * 32;
+
+    for (int t = tid; t < KMAX; t += 64 * NW) rows[t] = t < p.K ? (p.bgather ? p.bgather[t] : t) : -1;
+    for (int u = tid; u < RA * (KMAX / 4); u += 64 * NW) {
+        const int r = u / (KMAX / 4), k = 4 * (u % (KMAX / 4));
+        const int m = m0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) {
+            const float* src = p.A + (int64_t)m * p.lda + k;
+            if (k + 3 < p.K) v = *reinterpret_cast<const f32x4*>(src);
+            else {
+                v.x = k < p.K ? src[0] : 0.f;
+                v.y = k + 1 < p.K ? src[1] : 0.f;
+                v.z = k + 2 < p.K ? src[2] : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(As + r * LDA + k) = v;
+    }
+    __syncthreads();
+    if (n0 >= p.N) return;                       // wave-uniform; no barrier below
+
+    const int n = min(n0 + i, p.N - 1);
+    const bool nok = n0 + i < p.N;
+    float xb[KMAX / 2];
+#pragma unroll
+    for (int s = 0; s < KMAX / 8; ++s) {
+        const int4 rr = *reinterpret_cast<const int4*>(rows + 8 * s + 4 * h);
+        xb[4 * s + 0] = rr.x >= 0 ? p.B[(int64_t)rr.x * p.ldb + n] : 0.f;
+        xb[4 * s + 1] = rr.y >= 0 ? p.B[(int64_t)rr.y * p.ldb + n] : 0.f;
+        xb[4 * s + 2] = rr.z >= 0 ? p.B[(int64_t)rr.z * p.ldb + n] : 0.f;
+        xb[4 * s + 3] = rr.w >= 0 ? p.B[(int64_t)rr.w * p.ldb + n] : 0.f;
+    }
+
+#pragma unroll 1
+    for (int lt = 0; lt < LT; ++lt) {
+        const int mb = m0 + 32 * lt;
+        if (mb >= p.M) break;
+        float w[16], mm[16], vv[16];
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            ok[r] = nok && m < p.M;
+            if (EPI == OV_EPI_ADAMW) {
+                const int64_t idx = (int64_t)m * p.ldc + n;
+                w[r] = ok[r] ? p.C[idx] : 0.f;
+                mm[r] = ok[r] ? p.Pm[idx] : 0.f;
+                vv[r] = ok[r] ? p.Pv[idx] : 0.f;
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* arow = As + (32 * lt + i) * LDA + 4 * h;
+#pragma unroll
+        for (int s = 0; s < KMAX / 8; ++s) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + 8 * s);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], xb[4 * s + t], acc, 0, 0, 0);
+        }
+        if (EPI == OV_EPI_ADAMW) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ov_adamw(w[r], mm[r], vv[r], acc[r], p.adam, false);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t idx = (int64_t)m * p.ldc + n;
+                if (ok[r]) { p.C[idx] = w[r]; p.Pm[idx] = mm[r]; p.Pv[idx] = vv[r]; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (ok[r]) p.C[(int64_t)m * p.ldc + n] = acc[r];
             }
         }
     }

@@ -1204,6 +1204,22 @@ static int ov_launch_gemm_lds(const OvGemm& g, int S, hipStream_t st) {
 
 static inline bool ov_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// dW0 with the x fragment resident in registers (K <= 128, dh rows 16-B aligned)
+template <int EPI>
+static int ov_launch_dw0(const OvGemm& g, hipStream_t st) {
+    constexpr int NW = 8;
+    if (g.K > 128 || (g.lda & 3) || !ov_al16(g.A)) { ontovae_set_error("dw0: needs K <= 128 and 16-B aligned dh rows"); return ONTOVAE_EINVAL; }
+    const int njobs = (g.M + 127) / 128;
+    const int gxn = (g.N + 32 * NW - 1) / (32 * NW);
+    const int blocks = (gxn + 7) / 8 * 8 * njobs;
+    const size_t lds = (size_t)128 * 132 * sizeof(float) + 128 * sizeof(int32_t);
+    auto kern = ov_dw0_kernel<NW, EPI>;
+    OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, g, njobs);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
 struct OvStep {
     const ontovae_ctx_t* c;
     OvWs ws;
@@ -1664,19 +1680,23 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     g.B = s.x; g.ldb = s.xld; g.bgather = s.xidx;     // B(k=b, n=g) = X[row(b) * G + g]
     g.ldc = d.G; g.kchunk = (s.B + 31) / 32 * 32;
     g.adam = ov_adam_from(opt);
-    g.dbg = (c->flags >> 16) & 3;
+    g.dbg = (c->flags >> 16) & 7;
     OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
+    const bool resident = s.B <= 128 && (s.ldb % 4 == 0) && ov_al16(g.A) && !((c->flags >> 22) & 1);
     if (apply) {
         g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
+        if (resident) return ov_launch_dw0<OV_EPI_ADAMW>(g, s.st);
         const int var = (c->flags >> 12) & 3;
         const bool al = (d.G % 4 == 0) && ov_al16(g.C) && ov_al16(g.Pm) && ov_al16(g.Pv);
         if (al && ov_al16(g.B) && ((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_ADAMW>(g, 1, s.st);
-        if (!al || var == 1) return ov_launch_gemm<1, 1, 1, 4, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
+        if (!al || var == 0) return ov_launch_gemm<1, 1, 1, 4, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
+        if (var == 1) return ov_launch_gemm<1, 2, 1, 2, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
         if (var == 2) return ov_launch_gemm<1, 2, 1, 2, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
         if (var == 3) return ov_launch_gemm<1, 4, 1, 1, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
         return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
     }
     g.C = c->Gr + c->lay.W0;
+    if (resident) return ov_launch_dw0<OV_EPI_STORE>(g, s.st);
     if ((d.G % 4 == 0) && ov_al16(g.B) && ((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_STORE>(g, 1, s.st);
     return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_STORE>(g, 1, true, s.st);
 }
