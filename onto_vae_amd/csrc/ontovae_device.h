@@ -52,6 +52,16 @@ __device__ __forceinline__ void ov_adamw(float& w, float& m, float& v, float g, 
     if (clamp0) w = fmaxf(w, 0.0f);               // vae_model.py:175-176
 }
 
+// same update with the hardware reciprocal / square root (1 ulp each) in place of the IEEE sequences
+__device__ __forceinline__ void ov_adamw_fast(float& w, float& m, float& v, float g, const OvAdam& h, bool clamp0) {
+    w = w * h.decay_mul;
+    m = m + (g - m) * h.one_m_beta1;
+    v = v * h.beta2 + (h.one_m_beta2 * g) * g;
+    const float denom = __builtin_amdgcn_sqrtf(v) * __builtin_amdgcn_rcpf(h.bc2_sqrt) + h.eps;
+    w = w + (-h.step_size * m) * __builtin_amdgcn_rcpf(denom);
+    if (clamp0) w = fmaxf(w, 0.0f);
+}
+
 // ---- Philox4x32-10 counter RNG for dropout masks and internally drawn eps ------------------------
 struct OvPhilox {
     uint32_t c[4];

@@ -566,12 +566,38 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
 // Workgroups that share a gene range are given ids congruent mod 8, i.e. the same XCD, so the x tile is
 // fetched into one L2 only.
 // -------------------------------------------------------------------------------------------------
+// Bounds-checked buffer access for the parameter stream: a row beyond M or a column beyond N becomes an
+// offset beyond num_records, which the hardware reads as 0 and does not store, so partial tiles need no
+// branches.  (Vector memory path; offsets are 32-bit, the host checks M * ldc * 4 < 2^31.)
+typedef int32_t ov_i32x4 __attribute__((ext_vector_type(4)));
+__device__ float ov_buf_load(ov_i32x4 rsrc, int32_t voffset, int32_t soffset, int32_t aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void ov_buf_store(float v, ov_i32x4 rsrc, int32_t voffset, int32_t soffset, int32_t aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ __forceinline__ ov_i32x4 ov_buf_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    ov_i32x4 r;
+    r.x = (int32_t)(uint32_t)a;
+    r.y = (int32_t)((uint32_t)(a >> 32) & 0xffffu);      // stride 0: raw buffer
+    r.z = (int32_t)bytes;
+    r.w = 0x00020000;                                     // 32-bit untyped data format (gfx90a / gfx94x / gfx950)
+    return r;
+}
+
+#ifdef OV_DW0_PROBE      // scratch/dw0_probe.hip: per-wave timestamps into p.bias (16 x uint64 per wave)
+#define OV_PROBE(slot) do { probe_t[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define OV_PROBE(slot) do { } while (0)
+#endif
+
 template <int NW, int EPI>
 __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njobs) {
+#ifdef OV_DW0_PROBE
+    uint64_t probe_t[16] = {};
+#endif
+    OV_PROBE(0);
     constexpr int LT = 4, RA = 32 * LT, KMAX = 128, LDA = KMAX + 4;
     extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
     float* As = ov_gemm_lds;                                             // [RA][LDA]
-    int32_t* rows = reinterpret_cast<int32_t*>(ov_gemm_lds + RA * LDA);  // [KMAX], -1 beyond K
+    int32_t* rows = reinterpret_cast<int32_t*>(ov_gemm_lds + RA * LDA);  // [KMAX]; beyond K: the last row (dh is 0 there)
     const int tid = threadIdx.x;
     const int lane = ov_lane();
     const int wave = ov_wave_id();
@@ -581,9 +607,40 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
     const int gx = (b / (8 * njobs)) * 8 + (b & 7);
     const int m0 = job * RA;
     const int n0 = (gx * NW + wave) * 32;
+    const bool wave_on = n0 < p.N;
+    const uint32_t row_bytes = (uint32_t)p.ldc * 4u;
+    // element (r, lane) of the tile at row mb: a per-row descriptor (scalar registers: base + row offset, the
+    // bytes that remain) and ONE lane offset for all rows
+    const int32_t lane_off = n0 + i < p.N ? (int32_t)(((uint32_t)(4 * h) * (uint32_t)p.ldc + (uint32_t)(n0 + i)) * 4u) : (int32_t)0x80000000u;
+    auto row_rsrc = [&](const float* base, int mb, int r) {
+        const int row = mb + (r & 3) + 8 * (r >> 2);
+        const uint32_t ro = (uint32_t)row * row_bytes;
+        return ov_buf_rsrc(reinterpret_cast<const char*>(base) + ro, (uint32_t)max(p.M - row, 0) * row_bytes);
+    };
 
-    for (int t = tid; t < KMAX; t += 64 * NW) rows[t] = t < p.K ? (p.bgather ? p.bgather[t] : t) : -1;
-    for (int u = tid; u < RA * (KMAX / 4); u += 64 * NW) {
+    // parameter / moment registers of two tiles: tile lt + 1 is requested before the MFMAs of tile lt
+    float w[2][16], mm[2][16], vv[2][16];
+    auto request = [&](int buf, int lt) {
+        if (EPI != OV_EPI_ADAMW) return;
+        const int mb = m0 + 32 * lt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#ifdef OV_DW0_NOLOAD
+            w[buf][r] = mm[buf][r] = vv[buf][r] = (float)(lane + r);
+#else
+            w[buf][r] = ov_buf_load(row_rsrc(p.C, mb, r), lane_off, 0, 0);
+            mm[buf][r] = ov_buf_load(row_rsrc(p.Pm, mb, r), lane_off, 0, 0);
+            vv[buf][r] = ov_buf_load(row_rsrc(p.Pv, mb, r), lane_off, 0, 0);
+#endif
+        }
+    };
+    // Prologue, ordered by what the first MFMA needs (memory returns in issue order): the dh slab and the
+    // x fragment first, then the first tile's parameters; the slab goes to LDS once it has landed.
+    constexpr int SU = RA * (KMAX / 4) / (64 * NW);
+    f32x4 sv[SU];
+#pragma unroll
+    for (int q = 0; q < SU; ++q) {
+        const int u = tid + q * 64 * NW;
         const int r = u / (KMAX / 4), k = 4 * (u % (KMAX / 4));
         const int m = m0 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -596,40 +653,41 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
                 v.z = k + 2 < p.K ? src[2] : 0.f;
             }
         }
-        *reinterpret_cast<f32x4*>(As + r * LDA + k) = v;
+        sv[q] = v;
+    }
+    for (int t = tid; t < KMAX; t += 64 * NW) {
+        const int tt = min(t, p.K - 1);
+        rows[t] = p.bgather ? p.bgather[tt] : tt;
     }
     __syncthreads();
-    if (n0 >= p.N) return;                       // wave-uniform; no barrier below
-
-    const int n = min(n0 + i, p.N - 1);
-    const bool nok = n0 + i < p.N;
+    OV_PROBE(1);
     float xb[KMAX / 2];
+    if (wave_on) {
+        const float* xcol = p.B + min(n0 + i, p.N - 1);
 #pragma unroll
-    for (int s = 0; s < KMAX / 8; ++s) {
-        const int4 rr = *reinterpret_cast<const int4*>(rows + 8 * s + 4 * h);
-        xb[4 * s + 0] = rr.x >= 0 ? p.B[(int64_t)rr.x * p.ldb + n] : 0.f;
-        xb[4 * s + 1] = rr.y >= 0 ? p.B[(int64_t)rr.y * p.ldb + n] : 0.f;
-        xb[4 * s + 2] = rr.z >= 0 ? p.B[(int64_t)rr.z * p.ldb + n] : 0.f;
-        xb[4 * s + 3] = rr.w >= 0 ? p.B[(int64_t)rr.w * p.ldb + n] : 0.f;
-    }
-
-#pragma unroll 1
-    for (int lt = 0; lt < LT; ++lt) {
-        const int mb = m0 + 32 * lt;
-        if (mb >= p.M) break;
-        float w[16], mm[16], vv[16];
-        bool ok[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
-            ok[r] = nok && m < p.M;
-            if (EPI == OV_EPI_ADAMW) {
-                const int64_t idx = (int64_t)m * p.ldc + n;
-                w[r] = ok[r] ? p.C[idx] : 0.f;
-                mm[r] = ok[r] ? p.Pm[idx] : 0.f;
-                vv[r] = ok[r] ? p.Pv[idx] : 0.f;
-            }
+        for (int s = 0; s < KMAX / 8; ++s) {
+            const int4 rr = *reinterpret_cast<const int4*>(rows + 8 * s + 4 * h);
+            xb[4 * s + 0] = xcol[(int64_t)rr.x * p.ldb];
+            xb[4 * s + 1] = xcol[(int64_t)rr.y * p.ldb];
+            xb[4 * s + 2] = xcol[(int64_t)rr.z * p.ldb];
+            xb[4 * s + 3] = xcol[(int64_t)rr.w * p.ldb];
         }
+    }
+    OV_PROBE(2);
+#pragma unroll
+    for (int q = 0; q < SU; ++q) {
+        const int u = tid + q * 64 * NW;
+        *reinterpret_cast<f32x4*>(As + (u / (KMAX / 4)) * LDA + 4 * (u % (KMAX / 4))) = sv[q];
+    }
+    __syncthreads();
+    if (!wave_on) return;                       // wave-uniform; no barrier below
+    request(0, 0);
+
+    // One tile: MFMAs, AdamW arithmetic, THEN the next tile's request, then this tile's stores.  The order
+    // keeps every wait exact: the hardware counts at most 63 outstanding vector memory operations, so a
+    // wait for "all but the youngest n" with n > 63 would degrade to waiting for much more.
+    auto tile = [&](int buf, int lt, bool more) {
+        const int mb = m0 + 32 * lt;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -637,26 +695,54 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
 #pragma unroll
         for (int s = 0; s < KMAX / 8; ++s) {
             const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + 8 * s);
+#ifdef OV_DW0_NOMFMA
+            if (s < 1)
+#endif
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], xb[4 * s + t], acc, 0, 0, 0);
         }
+        OV_PROBE(4 + 2 * (lt & 3));
         if (EPI == OV_EPI_ADAMW) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ov_adamw(w[r], mm[r], vv[r], acc[r], p.adam, false);
+            for (int r = 0; r < 16; ++r) {
+#if defined(OV_DW0_NOADAM)
+                w[buf][r] += acc[r]; mm[buf][r] += acc[r]; vv[buf][r] += acc[r];
+#elif defined(OV_DW0_IEEEADAM)
+                ov_adamw(w[buf][r], mm[buf][r], vv[buf][r], acc[r], p.adam, false);
+#else
+                ov_adamw_fast(w[buf][r], mm[buf][r], vv[buf][r], acc[r], p.adam, false);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) request(buf ^ 1, lt + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int64_t idx = (int64_t)m * p.ldc + n;
-                if (ok[r]) { p.C[idx] = w[r]; p.Pm[idx] = mm[r]; p.Pv[idx] = vv[r]; }
+                ov_buf_store(w[buf][r], row_rsrc(p.C, mb, r), lane_off, 0, 0);
+                ov_buf_store(mm[buf][r], row_rsrc(p.Pm, mb, r), lane_off, 0, 0);
+                ov_buf_store(vv[buf][r], row_rsrc(p.Pv, mb, r), lane_off, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (ok[r]) p.C[(int64_t)m * p.ldc + n] = acc[r];
-            }
+            for (int r = 0; r < 16; ++r) ov_buf_store(acc[r], row_rsrc(p.C, mb, r), lane_off, 0, 0);
         }
+        OV_PROBE(5 + 2 * (lt & 3));
+    };
+    OV_PROBE(3);
+#pragma unroll 1
+    for (int lt = 0; lt < LT && m0 + 32 * lt < p.M; lt += 2) {
+        const bool more1 = m0 + 32 * (lt + 1) < p.M;
+        tile(0, lt, more1);
+        if (!more1) break;
+        tile(1, lt + 1, lt + 2 < LT && m0 + 32 * (lt + 2) < p.M);
     }
+    OV_PROBE(15);
+#ifdef OV_DW0_PROBE
+    if (lane == 0 && p.bias) {
+        uint64_t* out = reinterpret_cast<uint64_t*>(const_cast<float*>(p.bias)) + ((int64_t)blockIdx.x * NW + wave) * 16;
+        for (int q = 0; q < 16; ++q) out[q] = probe_t[q];
+    }
+#endif
 }
 
 #endif

@@ -1208,7 +1208,10 @@ static inline bool ov_al16(const void* p) { return (reinterpret_cast<uintptr_t>(
 template <int EPI>
 static int ov_launch_dw0(const OvGemm& g, hipStream_t st) {
     constexpr int NW = 8;
-    if (g.K > 128 || (g.lda & 3) || !ov_al16(g.A)) { ontovae_set_error("dw0: needs K <= 128 and 16-B aligned dh rows"); return ONTOVAE_EINVAL; }
+    if (g.K > 128 || (g.lda & 3) || !ov_al16(g.A) || (int64_t)g.M * g.ldc * 4 >= (int64_t)1 << 31) {
+        ontovae_set_error("dw0: needs K <= 128, 16-B aligned dh rows and a parameter below 2 GiB");
+        return ONTOVAE_EINVAL;
+    }
     const int njobs = (g.M + 127) / 128;
     const int gxn = (g.N + 32 * NW - 1) / (32 * NW);
     const int blocks = (gxn + 7) / 8 * 8 * njobs;
@@ -1682,7 +1685,8 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     g.adam = ov_adam_from(opt);
     g.dbg = (c->flags >> 16) & 7;
     OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
-    const bool resident = s.B <= 128 && (s.ldb % 4 == 0) && ov_al16(g.A) && !((c->flags >> 22) & 1);
+    const bool resident = s.B <= 128 && (s.ldb % 4 == 0) && ov_al16(g.A) && (int64_t)d.L * d.G * 4 < ((int64_t)1 << 31) &&
+                          !((c->flags >> 22) & 1);
     if (apply) {
         g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
         if (resident) return ov_launch_dw0<OV_EPI_ADAMW>(g, s.st);
