@@ -29,8 +29,9 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s 
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 
 
-def phase_cost(name, d, B):
-    """Algorithmic (bytes, flops) of one launch-set of a phase per step; None where it is not modelled."""
+def phase_cost(name, d, B, nnz_t=0):
+    """Algorithmic (bytes, flops) of one launch-set of a phase per step; None where it is not modelled.
+    nnz_t = non-zeros of the term layers (rows of the node-space operator below C)."""
     L, G, C_, nnz = d.L, d.G, d.C, int(d.nnz)
     f = 4
     if name == "dw0":       # read dh + x, read+write w, m, v of W0 (fused AdamW); 2*L*G*B flops
@@ -41,8 +42,10 @@ def phase_cost(name, d, B):
         return (6 * nnz + nnz + (2 * C_ + G) * B) * f, 2.0 * nnz * B
     if name == "dec_fwd_gene":
         return (2 * nnz + C_ * B + 2 * G * B) * f, 2.0 * nnz * B
-    if name == "dec_bwd":
-        return (3 * nnz + (C_ + G) * B) * f, 2.0 * nnz * B
+    if name == "dec_bwd_gene":   # gene-layer links: value + row index + k; D gene rows read, D panel rows written
+        return (3 * (nnz - nnz_t) + (C_ + G) * B) * f, 2.0 * (nnz - nnz_t) * B
+    if name == "dec_bwd":        # term levels: packed link records once per 4-column panel pass, D panel read + written
+        return (2 * nnz_t * (B // 4) + 2 * C_ * B) * f, 2.0 * nnz_t * B
     return None
 
 
@@ -199,7 +202,7 @@ def main():
 
     if rank == 0:
         value = Bg * a.steps / dt
-        cost = phase_cost(dom, d, B)
+        cost = phase_cost(dom, d, B, int(e.plan.rowptr[d.C]))
         roof = None
         if cost is not None:
             nbytes, flops = cost

@@ -292,7 +292,7 @@ enum {
     ONTOVAE_PHASE_REPARAM = 3,       /* z_drop, reparameterisation, KL              */
     ONTOVAE_PHASE_DEC_FWD_TERMS = 4, /* term levels of the decoder (K-1 launches)   */
     ONTOVAE_PHASE_DEC_FWD_GENE = 5,  /* gene layer + ELBO epilogue                  */
-    ONTOVAE_PHASE_DEC_BWD = 6,       /* decoder backward data (K launches)          */
+    ONTOVAE_PHASE_DEC_BWD = 6,       /* decoder backward data, term levels          */
     ONTOVAE_PHASE_LOSS = 7,          /* loss partial reduction                      */
     ONTOVAE_PHASE_DEC_WGRAD = 8,     /* decoder weight gradient + AdamW + clamp     */
     ONTOVAE_PHASE_LATENT_BWD = 9,    /* d mu, d log_var                             */
@@ -300,7 +300,9 @@ enum {
     ONTOVAE_PHASE_DWH = 11,          /* heads weight gradient + AdamW               */
     ONTOVAE_PHASE_BN_BWD = 12,       /* BatchNorm backward + AdamW of gamma/beta/b0 */
     ONTOVAE_PHASE_DW0 = 13,          /* dW0 = dh x (MFMA) + fused AdamW             */
-    ONTOVAE_PHASE_COUNT = 14
+    ONTOVAE_PHASE_DEC_BWD_GENE = 14, /* decoder backward data, gene layer           */
+    ONTOVAE_PHASE_SELL_REFRESH = 15, /* packed term-level weight copies <- params   */
+    ONTOVAE_PHASE_COUNT = 16
 };
 int ontovae_profile_begin(uint32_t phase_mask, int32_t capacity);
 int ontovae_profile_read(int32_t phase, float* ms, int32_t cap, int32_t* n_out);

@@ -124,7 +124,7 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end"]
 
 PHASES = ["enc_gemm", "bn_fwd", "heads", "reparam", "dec_fwd_terms", "dec_fwd_gene", "dec_bwd", "loss", "dec_wgrad",
-          "latent_bwd", "da_gemm", "dwh", "bn_bwd", "dw0"]
+          "latent_bwd", "da_gemm", "dwh", "bn_bwd", "dw0", "dec_bwd_gene", "sell_refresh"]
 
 
 def check(rc, what=""):

@@ -1347,6 +1347,7 @@ static int ov_sell_refresh(OvStep& s) {
     const ontovae_sell_t& b = c->sell_bwd;
     const int nf = f.n_chunks * 512, nbf = f.n_slices * 64, nb = b.n_chunks * 512;
     const int blocks = std::min(512, (std::max(nf, nb) + 255) / 256);
+    OvProfScope prof(ONTOVAE_PHASE_SELL_REFRESH, s.st);
     hipLaunchKernelGGL(ov_sell_refresh_kernel, dim3(blocks), dim3(256), 0, s.st, c->P + c->lay.dec_vals, c->P + c->lay.dec_bias,
                        f.k, f.w, nf, f.node, f.bias, nbf, b.k, b.w, nb);
     OV_LAUNCH_CHECK();
@@ -1435,8 +1436,8 @@ static int ov_dec_backward(OvStep& s) {
         return ONTOVAE_OK;
     }
     const float* vals = c->P + c->lay.dec_vals;
-    OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
     {
+        OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
         dim3 grid((d.C + 3) / 4, s.nchunk);
 #define OV_BG(V) hipLaunchKernelGGL((ov_dec_bwd_gene_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row, c->csc_k, vals, s.ws.d, d.C, s.ldb)
         if (s.vec == 1) OV_BG(1); else if (s.vec == 2) OV_BG(2); else OV_BG(4);
@@ -1448,6 +1449,7 @@ static int ov_dec_backward(OvStep& s) {
     lv.n = sb.n_levels;
     for (int i = 0; i < lv.n; ++i) { lv.first[i] = sb.level_first[i]; lv.count[i] = sb.level_count[i]; }
     const size_t lds = (size_t)d.C * bt * sizeof(float);
+    OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
 #define OV_TB(BT)                                                                                                     \
     if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true>, lds))) return rc;                                              \
     hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true>), dim3(s.ldb / BT), dim3(1024), lds, s.st, sb.node, sb.info, sb.chunk0, \

@@ -24,4 +24,4 @@ def run(flags, n=30):
     L.ontovae_profile_end()
     return out
 for fl in [int(a,0) for a in sys.argv[1:]] or [0]:
-    r = run(fl); print(hex(fl), {k: r[k] for k in ('enc_gemm','bn_fwd','dw0','dwh','da_gemm','heads')}, 'sum', round(sum(r.values()),1))
+    r = run(fl); print(hex(fl), r, 'sum', round(sum(r.values()),1))
