@@ -1231,7 +1231,58 @@ struct OvStep {
     const float* x;
     const int32_t* xidx;
     int64_t xld;
+    struct OvSide* side;     // internal second stream of this device, or NULL (ONTOVAE_FLAG_SINGLE_STREAM / creation failed)
 };
+
+// Independent branches of a step run on a library-owned second stream, forked from and joined back into
+// the caller's stream with events, so the caller still sees one stream-ordered operation:
+//   forward : packed decoder weight refresh            || encoder
+//   backward: loss, decoder weight gradient, dWh/dbh   || latent backward, da, BatchNorm backward, dW0
+// One side stream and its events per device, created on first use and kept until the process ends.
+struct OvSide {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
+    bool tried = false, ok = false;
+};
+static OvSide g_side[64];
+
+static OvSide* ov_side_get(const ontovae_ctx_t* c) {
+    if (c->flags & ONTOVAE_FLAG_SINGLE_STREAM) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    OvSide& s = g_side[dev];
+    if (!s.tried) {
+        s.tried = true;
+        s.ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.mid, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+        if (!s.ok) (void)hipGetLastError();
+    }
+    return s.ok ? &s : nullptr;
+}
+// side stream starts after everything enqueued on the caller's stream so far
+static int ov_side_fork(OvStep& s) {
+    if (!s.side) return ONTOVAE_OK;
+    OV_HIP_CHECK(hipEventRecord(s.side->fork, s.st));
+    OV_HIP_CHECK(hipStreamWaitEvent(s.side->st, s.side->fork, 0));
+    return ONTOVAE_OK;
+}
+// side stream additionally waits for what the caller's stream holds now
+static int ov_side_sync_mid(OvStep& s) {
+    if (!s.side) return ONTOVAE_OK;
+    OV_HIP_CHECK(hipEventRecord(s.side->mid, s.st));
+    OV_HIP_CHECK(hipStreamWaitEvent(s.side->st, s.side->mid, 0));
+    return ONTOVAE_OK;
+}
+// caller's stream waits for the side stream's work
+static int ov_side_join(OvStep& s) {
+    if (!s.side) return ONTOVAE_OK;
+    OV_HIP_CHECK(hipEventRecord(s.side->join, s.side->st));
+    OV_HIP_CHECK(hipStreamWaitEvent(s.st, s.side->join, 0));
+    return ONTOVAE_OK;
+}
+static inline hipStream_t ov_side_stream(const OvStep& s) { return s.side ? s.side->st : s.st; }
 
 // x W0^T -> split-K slabs  (modules.py:46)
 static int ov_enc_gemm(OvStep& s, int* S_out) {
@@ -1340,21 +1391,22 @@ static int ov_set_lds(KernelT kernel, size_t bytes) {
 }
 
 // SELL weight copies <- parameter buffer; called once per pass before the first chain kernel
-static int ov_sell_refresh(OvStep& s) {
+static int ov_sell_refresh(OvStep& s, hipStream_t st) {
     const ontovae_ctx_t* c = s.c;
     if (ov_fused_bt(c) == 0) return ONTOVAE_OK;
     const ontovae_sell_t& f = c->sell_fwd;
     const ontovae_sell_t& b = c->sell_bwd;
     const int nf = f.n_chunks * 512, nbf = f.n_slices * 64, nb = b.n_chunks * 512;
     const int blocks = std::min(512, (std::max(nf, nb) + 255) / 256);
-    OvProfScope prof(ONTOVAE_PHASE_SELL_REFRESH, s.st);
-    hipLaunchKernelGGL(ov_sell_refresh_kernel, dim3(blocks), dim3(256), 0, s.st, c->P + c->lay.dec_vals, c->P + c->lay.dec_bias,
+    OvProfScope prof(ONTOVAE_PHASE_SELL_REFRESH, st);
+    hipLaunchKernelGGL(ov_sell_refresh_kernel, dim3(blocks), dim3(256), 0, st, c->P + c->lay.dec_vals, c->P + c->lay.dec_bias,
                        f.k, f.w, nf, f.node, f.bias, nbf, b.k, b.w, nb);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
 
-static int ov_dec_forward_terms(OvStep& s) {
+// refreshed = the packed weight copies were already refreshed for this pass (on the side stream, joined)
+static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     const int bt = ov_fused_bt(c);
@@ -1366,7 +1418,7 @@ static int ov_dec_forward_terms(OvStep& s) {
         return ONTOVAE_OK;
     }
     int rc;
-    if ((rc = ov_sell_refresh(s))) return rc;
+    if (!refreshed && (rc = ov_sell_refresh(s, s.st))) return rc;
     const ontovae_sell_t& f = c->sell_fwd;
     OvLevels lv;
     lv.n = f.n_levels;
@@ -1460,9 +1512,9 @@ static int ov_dec_backward(OvStep& s) {
     return ONTOVAE_OK;
 }
 
-static int ov_loss_finalize(OvStep& s, int nrec, int nkl, float kc, float* loss_out) {
-    OvProfScope prof(ONTOVAE_PHASE_LOSS, s.st);
-    hipLaunchKernelGGL(ov_loss_finalize_kernel, dim3(1), dim3(1024), 0, s.st, s.ws.rec_part, nrec, s.ws.kl_part, nkl, kc, loss_out);
+static int ov_loss_finalize(OvStep& s, hipStream_t st, int nrec, int nkl, float kc, float* loss_out) {
+    OvProfScope prof(ONTOVAE_PHASE_LOSS, st);
+    hipLaunchKernelGGL(ov_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, s.ws.rec_part, nrec, s.ws.kl_part, nkl, kc, loss_out);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
@@ -1478,6 +1530,7 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->x = x;
     s->xidx = xidx;
     s->xld = ctx->dims.G;
+    s->side = nullptr;
     return ONTOVAE_OK;
 }
 
@@ -1526,12 +1579,11 @@ extern "C" int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const
     if (!x || !loss_out) { ontovae_set_error("eval_step: x or loss_out is NULL"); return ONTOVAE_EINVAL; }
     OvStep s;
     ov_make_step(ctx, x, xidx, B, stream, &s);
-    const ontovae_dims_t& d = ctx->dims;
     int nkl = 0;
     if ((rc = ov_encode(s, eps, 0, rng_offset, OV_RNG_EPS, 1, &nkl))) return rc;
     if ((rc = ov_dec_forward_terms(s))) return rc;
     if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
-    return ov_loss_finalize(s, ov_nrec(s), nkl, kl_coeff, loss_out);
+    return ov_loss_finalize(s, s.st, ov_nrec(s), nkl, kl_coeff, loss_out);
 }
 
 static int ov_act_out(OvStep& s, int lvl_from, int lvl_to, float* act_out, int64_t act_ld) {
@@ -1594,8 +1646,10 @@ extern "C" int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z,
 // =================================================================================================
 // Everything after the encoder forward: decoder, ELBO, full backward, weight gradients.
 // bn_mode: 1 = fused BN backward (single GPU), 2 = stop after the DP phase-1 BN partial sums.
+// refreshed: ov_sell_refresh was already enqueued on the side stream (joined here before the decoder).
+// The side stream is still running when this returns: the caller ends the step with ov_side_join.
 static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float kc, const ontovae_adamw_t* opt, int apply,
-                           float* loss_out, int bn_mode, float* bn_bwd_stats, int Bglobal) {
+                           float* loss_out, int bn_mode, float* bn_bwd_stats, int Bglobal, bool refreshed) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     const ontovae_layout_t& lay = c->lay;
@@ -1603,17 +1657,21 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     int rc, nkl = 0;
     if ((rc = ov_heads_fwd(s))) return rc;
     if ((rc = ov_reparam(s, eps, 1, rng_off, OV_RNG_EPS, 1, &nkl))) return rc;
-    if ((rc = ov_dec_forward_terms(s))) return rc;
+    if (refreshed && (rc = ov_side_join(s))) return rc;          // packed decoder weights ready
+    if ((rc = ov_dec_forward_terms(s, refreshed))) return rc;
     if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
     if ((rc = ov_dec_backward(s))) return rc;
-    if ((rc = ov_loss_finalize(s, ov_nrec(s), nkl, kc, loss_out))) return rc;
+    // fork: the decoder's weight gradients and the loss need nothing from the encoder backward, and vice versa
+    if ((rc = ov_side_fork(s))) return rc;
+    const hipStream_t sst = ov_side_stream(s);
+    if ((rc = ov_loss_finalize(s, sst, ov_nrec(s), nkl, kc, loss_out))) return rc;
     // decoder weight gradients (+ AdamW + clamp)
     {
         const int n_term_rows = d.C - d.L;
         const int nrows = n_term_rows + d.G;
         float* G_ = c->Gr;
-        OvProfScope prof(ONTOVAE_PHASE_DEC_WGRAD, s.st);
-        hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s.st, c->rowptr, c->colidx, s.ws.act, s.ws.d,
+        OvProfScope prof(ONTOVAE_PHASE_DEC_WGRAD, sst);
+        hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((nrows + 3) / 4), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act, s.ws.d,
                            c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                            G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
                            c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, nrows, 0, n_term_rows, d.C, s.ldb,
@@ -1639,7 +1697,8 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         OvProfScope prof(ONTOVAE_PHASE_DA_GEMM, s.st);
         if ((rc = ov_launch_gemm<1, 1, 4, 4, false, false, OV_EPI_STORE>(g, 1, false, s.st))) return rc;
     }
-    // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv)
+    // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv): side stream, after da has read Wh
+    if ((rc = ov_side_sync_mid(s))) return rc;
     {
         OvGemm g{};
         g.M = 2 * d.L; g.N = d.L; g.K = s.B;
@@ -1647,15 +1706,15 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         g.B = s.ws.a; g.ldb = s.ldb;
         g.ldc = d.L; g.kchunk = (s.B + 31) / 32 * 32;
         g.adam = adam;
-        OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
+        OvProfScope prof(ONTOVAE_PHASE_DWH, sst);
         if (apply) {
             g.C = c->P + lay.Wh; g.Pm = c->M + lay.Wh; g.Pv = c->V + lay.Wh;
-            if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_ADAMW>(g, 1, true, s.st))) return rc;
+            if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_ADAMW>(g, 1, true, sst))) return rc;
         } else {
             g.C = c->Gr + lay.Wh;
-            if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_STORE>(g, 1, true, s.st))) return rc;
+            if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_STORE>(g, 1, true, sst))) return rc;
         }
-        hipLaunchKernelGGL(ov_rowsum_adamw_kernel, dim3((2 * d.L + 3) / 4), dim3(256), 0, s.st, s.ws.dmulv, 2 * d.L, s.ldb,
+        hipLaunchKernelGGL(ov_rowsum_adamw_kernel, dim3((2 * d.L + 3) / 4), dim3(256), 0, sst, s.ws.dmulv, 2 * d.L, s.ldb,
                            c->P + lay.bh, c->M ? c->M + lay.bh : nullptr, c->V ? c->V + lay.bh : nullptr,
                            c->Gr ? c->Gr + lay.bh : nullptr, apply, adam);
         OV_LAUNCH_CHECK();
@@ -1718,11 +1777,19 @@ extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, cons
     if (B < 2) { ontovae_set_error("train_step: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
     OvStep s;
     ov_make_step(ctx, x, xidx, B, stream, &s);
+    s.side = ov_side_get(ctx);
+    bool refreshed = false;
+    if (s.side && ov_fused_bt(ctx) != 0) {      // packed decoder weight copies || encoder
+        if ((rc = ov_side_fork(s))) return rc;
+        if ((rc = ov_sell_refresh(s, s.side->st))) return rc;
+        refreshed = true;
+    }
     int S = 1;
     if ((rc = ov_enc_gemm(s, &S))) return rc;
     if ((rc = ov_bn_fwd(s, S, 1, B, nullptr, rng_offset))) return rc;
-    if ((rc = ov_train_tail_a(s, eps, rng_offset, kl_coeff, opt, apply_update, loss_out, 1, nullptr, B))) return rc;
-    return ov_dw0(s, opt, apply_update);
+    if ((rc = ov_train_tail_a(s, eps, rng_offset, kl_coeff, opt, apply_update, loss_out, 1, nullptr, B, refreshed))) return rc;
+    if ((rc = ov_dw0(s, opt, apply_update))) return rc;
+    return ov_side_join(s);
 }
 
 extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, const float* x, const int32_t* xidx, int32_t B,
@@ -1740,7 +1807,9 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
         return ov_bn_fwd(s, S, 2, B_global, bn_stats, rng_offset);
     } else if (phase == 1) {
         if ((rc = ov_bn_fwd(s, 1, 3, B_global, bn_stats, rng_offset))) return rc;
-        return ov_train_tail_a(s, eps, rng_offset, kl_coeff, nullptr, 0, loss_out, 2, bn_bwd_stats, B_global);
+        s.side = ov_side_get(ctx);
+        if ((rc = ov_train_tail_a(s, eps, rng_offset, kl_coeff, nullptr, 0, loss_out, 2, bn_bwd_stats, B_global, false))) return rc;
+        return ov_side_join(s);
     } else if (phase == 2) {
         const ontovae_dims_t& d = ctx->dims;
         const ontovae_layout_t& lay = ctx->lay;
