@@ -730,6 +730,7 @@ __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __res
 #define OV_RL_F(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (l)))
 
 // acc[VEC] += sum over entries [k0, k1) of w * src[row(entry) * ldb + boff ..]
+#define OV_GATHER_U 16      // row loads in flight per lane (64 % OV_GATHER_U == 0)
 template <int VEC, bool INDIRECT>
 __device__ __forceinline__ void ov_gather_rows_acc(float (&acc)[VEC], int k0, int k1, const int32_t* __restrict__ rowidx,
                                                    const int32_t* __restrict__ kidx, const float* __restrict__ vals,
@@ -741,16 +742,16 @@ __device__ __forceinline__ void ov_gather_rows_acc(float (&acc)[VEC], int k0, in
         const int my_r = rowidx[base + min(lane, cnt - 1)];
         float my_w = 0.f;
         if (lane < cnt) my_w = INDIRECT ? vals[kidx[base + lane]] : vals[base + lane];
-        for (int u = 0; u < cnt; u += 8) {
-            float v[8][VEC], w[8];
+        for (int u = 0; u < cnt; u += OV_GATHER_U) {
+            float v[OV_GATHER_U][VEC], w[OV_GATHER_U];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < OV_GATHER_U; ++t) {
                 const int r = OV_RL_I(my_r, u + t);
                 w[t] = OV_RL_F(my_w, u + t);
                 ov_ldv<VEC>(src + (int64_t)r * ldb + boff, v[t]);
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < OV_GATHER_U; ++t)
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[j] += w[t] * v[t][j];
         }
@@ -864,6 +865,240 @@ __global__ __launch_bounds__(512) void ov_dec_gene_tile_kernel(const int32_t* __
     }
 }
 
+// =================================================================================================
+// Column-block kernels of the gene layer.
+//
+// The gathers of the gene layer (forward: 24 panel rows per gene; backward: ~55 gene rows per panel node)
+// move 512 B per non-zero through the L2 when a wave covers all 128 batch columns, and their working
+// sets (activation panel 4.6 MB, gene rows of D 10 MB at GO-BP scale) do not stay in one XCD's 4 MB L2:
+// measured hit rates were 40-68 % and the kernels ran at the pace of the fabric behind the L2.
+// Here the batch is cut into blocks of 32 columns (one 128-B line per row) and every block is given to
+// fixed XCDs (workgroup ids are dealt round-robin to the 8 XCDs), so an XCD's L2 only ever sees its own
+// 32 columns of the panel (1.15 MB) and of D (2.5 MB).
+//
+// A wave is 8 lane groups of 8 lanes; lane (grp = lane >> 3, s = lane & 7) owns columns col0 + 4 s .. + 3
+// of the row its group is working on, so one wave instruction gathers 8 different rows, 128 B each.
+// The 64 (index, weight) pairs of a pass are loaded coalesced in the permuted order e = 8 s + grp, which
+// puts the entry of group grp at step i into lane (grp, i): a ds_swizzle broadcast within the group
+// hands it out.  The 8 group partials are summed at the end (swizzle xor 8, 16, bpermute xor 32).
+// =================================================================================================
+struct OvCbMap { int cb, tile; };
+// workgroup id -> (column block, row tile); ncb is 1, 2, 4, 8 or a multiple of 8
+__device__ __forceinline__ OvCbMap ov_cb_map(int id, int ncb) {
+    const int xcd = id & 7, q = id >> 3;
+    OvCbMap m;
+    if (ncb <= 8) {
+        const int xpc = 8 / ncb;              // XCDs per column block
+        m.cb = xcd % ncb;
+        m.tile = q * xpc + xcd / ncb;
+    } else {
+        const int cpx = ncb >> 3;             // column blocks per XCD
+        m.cb = xcd + 8 * (q % cpx);
+        m.tile = q / cpx;
+    }
+    return m;
+}
+static int ov_cb_grid(int ncb, int ntiles) {
+    if (ncb <= 8) { const int xpc = 8 / ncb; return 8 * ((ntiles + xpc - 1) / xpc); }
+    return 8 * ntiles * (ncb >> 3);
+}
+
+template <int I>
+__device__ __forceinline__ int ov_grp_bcast(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x18 | (I << 5)); }
+template <int I>
+__device__ __forceinline__ float ov_grp_bcast(float v) { return __builtin_bit_cast(float, ov_grp_bcast<I>(__builtin_bit_cast(int, v))); }
+
+// sum of the 8 lane groups, per s; every lane ends with the total of its s
+__device__ __forceinline__ float ov_grp_reduce(float v, int lane) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1f | (8 << 10)));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1f | (16 << 10)));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __builtin_bit_cast(int, v)));
+    return v;
+}
+
+// acc (this group's partial) += sum over its share of entries [k0, k1) of w * src[row(entry) * ldb + 0..3];
+// srccol = src + col0 + 4 s.  k0, k1 are wave-uniform.
+template <bool INDIRECT>
+__device__ __forceinline__ void ov_gather_cb(f32x4& acc, int k0, int k1, const int32_t* __restrict__ rowidx,
+                                             const int32_t* __restrict__ kidx, const float* __restrict__ vals,
+                                             const float* __restrict__ srccol, int ldb, int lane) {
+    const int e = 8 * (lane & 7) + (lane >> 3);
+    for (int base = k0; base < k1; base += 64) {
+        const int cnt = min(64, k1 - base);
+        // lanes beyond cnt repeat the last entry's row with weight 0 (a row the list really names)
+        const int my_r = rowidx[base + min(e, cnt - 1)];
+        float my_w = 0.f;
+        if (e < cnt) my_w = INDIRECT ? vals[kidx[base + e]] : vals[base + e];
+        const int nsteps = (cnt + 7) >> 3;
+        f32x4 v[8];
+        float w[8];
+#define OV_CB_STEP(I)                                                                                     \
+        if (I < nsteps) {                                                                                 \
+            const int r = ov_grp_bcast<I>(my_r);                                                          \
+            w[I] = ov_grp_bcast<I>(my_w);                                                                 \
+            v[I] = *reinterpret_cast<const f32x4*>(srccol + (int64_t)r * ldb);                            \
+        }
+        OV_CB_STEP(0) OV_CB_STEP(1) OV_CB_STEP(2) OV_CB_STEP(3) OV_CB_STEP(4) OV_CB_STEP(5) OV_CB_STEP(6) OV_CB_STEP(7)
+#undef OV_CB_STEP
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nsteps) {
+                acc.x += w[i] * v[i].x; acc.y += w[i] * v[i].y; acc.z += w[i] * v[i].z; acc.w += w[i] * v[i].w;
+            }
+    }
+}
+
+// One row per lane group: acc += sum over entries [k0, k0 + len) of w * src[row(entry) * ldb + 0..3], where k0 and len
+// are per group.  Batches of 8 entries per group: the group's 8 lanes load 8 consecutive (index, weight) pairs, the
+// next batch is requested before the current one's row gathers, and a ds_swizzle broadcast within the group hands
+// entry i to all 8 lanes.  Groups whose list is shorter than the wave's longest re-read their last row with weight 0.
+template <bool INDIRECT>
+__device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const int32_t* __restrict__ rowidx,
+                                              const int32_t* __restrict__ kidx, const float* __restrict__ vals,
+                                              const float* __restrict__ srccol, int ldb, int lane) {
+    const int s = lane & 7;
+    int maxlen = len;                    // wave maximum of len
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    auto fetch = [&](int e, int& r, float& w) {
+        // entry e of this group's list; beyond the list: the last row (or row 0 of an empty list), weight 0
+        const int ee = max(min(e, len - 1), 0);
+        r = len > 0 ? rowidx[k0 + ee] : 0;
+        w = 0.f;
+        if (e < len) w = INDIRECT ? vals[kidx[k0 + e]] : vals[k0 + e];
+    };
+    int cur_r, nxt_r = 0;
+    float cur_w, nxt_w = 0.f;
+    fetch(s, cur_r, cur_w);
+    for (int b0 = 0; b0 < maxlen; b0 += 8) {
+        if (b0 + 8 < maxlen) fetch(b0 + 8 + s, nxt_r, nxt_w);
+        f32x4 v[8];
+        float w[8];
+#define OV_GRP_STEP(I)                                                                                    \
+        {                                                                                                 \
+            const int r = ov_grp_bcast<I>(cur_r);                                                         \
+            w[I] = ov_grp_bcast<I>(cur_w);                                                                \
+            v[I] = *reinterpret_cast<const f32x4*>(srccol + (int64_t)r * ldb);                            \
+        }
+        OV_GRP_STEP(0) OV_GRP_STEP(1) OV_GRP_STEP(2) OV_GRP_STEP(3) OV_GRP_STEP(4) OV_GRP_STEP(5) OV_GRP_STEP(6) OV_GRP_STEP(7)
+#undef OV_GRP_STEP
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc.x += w[i] * v[i].x; acc.y += w[i] * v[i].y; acc.z += w[i] * v[i].z; acc.w += w[i] * v[i].w;
+        }
+        cur_r = nxt_r; cur_w = nxt_w;
+    }
+}
+
+// Gene layer forward on a (32 genes) x (32 columns) tile: 4 waves, one gene per lane group (8 genes per wave).
+// MODE 1: training (D = 2 (recon - x), partial sums of squares); MODE 2: inference (recon stored sample-major).
+// x (sample-major) and recon go through an LDS transpose so that both sides move whole 128-B segments.
+template <int MODE>
+__global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                        const float* __restrict__ vals, const float* __restrict__ bias,
+                                                        const float* __restrict__ act, int B, int ldb,
+                                                        const float* __restrict__ x, const int32_t* __restrict__ xidx, int G,
+                                                        float* __restrict__ d, float* __restrict__ rec_part,
+                                                        float* __restrict__ rec_out, int64_t rec_ld, int C, int ncb, int ntiles) {
+    constexpr int TG = 32, LD = 33;
+    __shared__ float xs[TG * LD];
+    __shared__ float red[4];
+    const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
+    if (map.tile >= ntiles) {                      // workgroup-uniform
+        if (MODE == 1 && threadIdx.x == 0) rec_part[blockIdx.x] = 0.f;
+        return;
+    }
+    const int g0 = map.tile * TG, col0 = map.cb * 32;
+    const int lane = ov_lane();
+    const int wave = ov_wave_id();
+    const int tid = threadIdx.x;
+    const int s4 = 4 * (lane & 7);
+    const int gl = 8 * wave + (lane >> 3);
+    const int g = g0 + gl;
+    const int node = C + min(g, G - 1);
+    // the group's list first: everything else waits on it
+    const int k0 = rowptr[node];
+    const int len = g < G ? rowptr[node + 1] - k0 : 0;
+    if (MODE == 1) {
+        const int b = tid >> 3, j = tid & 7;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (col0 + b < B && g0 + 4 * j < G) {
+            const int64_t r = xidx ? (int64_t)xidx[col0 + b] : (int64_t)(col0 + b);
+            v = *reinterpret_cast<const f32x4*>(x + r * G + g0 + 4 * j);
+        }
+        xs[(4 * j + 0) * LD + b] = v.x;
+        xs[(4 * j + 1) * LD + b] = v.y;
+        xs[(4 * j + 2) * LD + b] = v.z;
+        xs[(4 * j + 3) * LD + b] = v.w;
+    }
+    const float bv = bias[node];
+    f32x4 acc = {bv, bv, bv, bv};
+    ov_gather_grp<false>(acc, k0, len, colidx, nullptr, vals, act + col0 + s4, ldb, lane);
+    if (MODE == 1) {
+        __syncthreads();
+        float sq = 0.f;
+        if (g < G) {
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float dv = 0.f;
+                if (col0 + s4 + c < B) {
+                    dv = acc[c] - xs[gl * LD + s4 + c];
+                    sq += dv * dv;
+                }
+                o[c] = 2.f * dv;
+            }
+            *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = o;
+        }
+        sq = ov_wave_sum(sq);
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) rec_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs[gl * LD + s4 + c] = acc[c];
+        __syncthreads();
+        const int b = tid >> 3, j = tid & 7;
+        if (col0 + b < B && g0 + 4 * j < G) {
+            f32x4 v;
+            v.x = xs[(4 * j + 0) * LD + b];
+            v.y = xs[(4 * j + 1) * LD + b];
+            v.z = xs[(4 * j + 2) * LD + b];
+            v.w = xs[(4 * j + 3) * LD + b];
+            *reinterpret_cast<f32x4*>(rec_out + (int64_t)(col0 + b) * rec_ld + g0 + 4 * j) = v;
+        }
+    }
+}
+
+// Gene part of the backward on 32-column blocks: D[p, cols] = sum over the genes g of column p of W[g, p] * D[g, cols].
+// 4 waves, 2 panel nodes per wave.
+__global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_split,
+                                                            const int32_t* __restrict__ csc_row, const int32_t* __restrict__ csc_k,
+                                                            const float* __restrict__ vals, float* __restrict__ d, int C, int ldb,
+                                                            int ncb, int ntiles) {
+    const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
+    if (map.tile >= ntiles) return;
+    const int lane = ov_lane();
+    const int col0 = map.cb * 32, s4 = 4 * (lane & 7);
+    const float* dcol = d + col0 + s4;
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        const int node = map.tile * 8 + ov_wave_id() * 2 + t;
+        if (node >= C) return;
+        const int k0 = __builtin_amdgcn_readfirstlane(csc_split[node]);
+        const int k1 = __builtin_amdgcn_readfirstlane(cscptr[node + 1]);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        ov_gather_cb<true>(acc, k0, k1, csc_row, csc_k, vals, dcol, ldb, lane);
+        f32x4 o;
+        o.x = ov_grp_reduce(acc.x, lane);
+        o.y = ov_grp_reduce(acc.y, lane);
+        o.z = ov_grp_reduce(acc.z, lane);
+        o.w = ov_grp_reduce(acc.w, lane);
+        if (lane < 8) *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = o;
+    }
+}
+
 // Backward data, one wave per (panel node of the level, batch chunk), CSC gather:
 //   D[p, :] = sum_q vals[csc_k[q]] * D[csc_row[q], :]
 template <int VEC>
@@ -909,6 +1144,8 @@ __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restri
 //   g_k = sum_b D[n, b] * ACT[colidx[k], b];   gb = sum_b D[n, b]
 // The padded batch columns of D are zero by construction, so no masking is needed in the dots.
 // The 64 lanes then update 64 consecutive packed weights at once (coalesced w, m, v traffic).
+#define OV_WGRAD_U 16      // row dots in flight per wave (64 % OV_WGRAD_U == 0)
+#define OV_WGRAD_NB 2      // 64-column blocks of the batch per trip
 __global__ __launch_bounds__(256) void ov_dec_wgrad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                                           const float* __restrict__ act, const float* __restrict__ d,
                                                           float* __restrict__ vals, float* __restrict__ mvals,
@@ -929,36 +1166,39 @@ __global__ __launch_bounds__(256) void ov_dec_wgrad_kernel(const int32_t* __rest
     gb = ov_wave_sum(gb);
     for (int kb = k0; kb < k1; kb += 64) {
         const int cnt = min(64, k1 - kb);
-        const int my_c = lane < cnt ? colidx[kb + lane] : 0;    // one coalesced index load per 64 entries
+        // one coalesced index load per 64 entries; lanes beyond cnt repeat the last entry (its row is re-read from L1)
+        const int my_c = colidx[kb + min(lane, cnt - 1)];
+        const int k = kb + lane;
+        float w = 0.f, m = 0.f, v = 0.f;
+        if (apply_update && lane < cnt) { w = vals[k]; m = mvals[k]; v = vvals[k]; }     // lands under the dots
         float mine = 0.f;
-        int j = 0;
-        for (; j + 4 <= cnt; j += 4) {          // four row dots in flight
-            const float* a0 = act + (int64_t)OV_RL_I(my_c, j) * ldb;
-            const float* a1 = act + (int64_t)OV_RL_I(my_c, j + 1) * ldb;
-            const float* a2 = act + (int64_t)OV_RL_I(my_c, j + 2) * ldb;
-            const float* a3 = act + (int64_t)OV_RL_I(my_c, j + 3) * ldb;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int b = lane; b < ldb; b += 64) {
-                const float dv = dr[b];
-                s0 += dv * a0[b]; s1 += dv * a1[b]; s2 += dv * a2[b]; s3 += dv * a3[b];
+        for (int b0 = 0; b0 < ldb; b0 += 64 * OV_WGRAD_NB) {      // one trip for batches up to 256 columns
+            float dv[OV_WGRAD_NB];
+#pragma unroll
+            for (int q = 0; q < OV_WGRAD_NB; ++q) dv[q] = b0 + 64 * q < ldb ? dr[b0 + 64 * q + lane] : 0.f;
+            for (int j = 0; j < cnt; j += OV_WGRAD_U) {          // OV_WGRAD_U row dots in flight
+                float av[OV_WGRAD_U][OV_WGRAD_NB], sacc[OV_WGRAD_U];
+#pragma unroll
+                for (int t = 0; t < OV_WGRAD_U; ++t) {
+                    const float* ar = act + (int64_t)OV_RL_I(my_c, j + t) * ldb + b0 + lane;
+#pragma unroll
+                    for (int q = 0; q < OV_WGRAD_NB; ++q) av[t][q] = b0 + 64 * q < ldb ? ar[64 * q] : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < OV_WGRAD_U; ++t) {
+                    sacc[t] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < OV_WGRAD_NB; ++q) sacc[t] += dv[q] * av[t][q];
+                }
+#pragma unroll
+                for (int t = 0; t < OV_WGRAD_U; ++t) {
+                    const float tot = ov_wave_sum(sacc[t]);
+                    mine += lane == j + t ? tot : 0.f;
+                }
             }
-            s0 = ov_wave_sum(s0); s1 = ov_wave_sum(s1); s2 = ov_wave_sum(s2); s3 = ov_wave_sum(s3);
-            mine = lane == j ? s0 : mine;
-            mine = lane == j + 1 ? s1 : mine;
-            mine = lane == j + 2 ? s2 : mine;
-            mine = lane == j + 3 ? s3 : mine;
-        }
-        for (; j < cnt; ++j) {
-            const float* ar = act + (int64_t)OV_RL_I(my_c, j) * ldb;
-            float sacc = 0.f;
-            for (int b = lane; b < ldb; b += 64) sacc += dr[b] * ar[b];
-            sacc = ov_wave_sum(sacc);
-            mine = lane == j ? sacc : mine;
         }
         if (lane < cnt) {
-            const int k = kb + lane;
             if (apply_update) {
-                float w = vals[k], m = mvals[k], v = vvals[k];
                 ov_adamw(w, m, v, mine, adam, true);
                 vals[k] = w; mvals[k] = m; vvals[k] = v;
             } else {
@@ -1444,10 +1684,17 @@ static int ov_dec_gene(OvStep& s, float* rec_out, int64_t rec_ld) {
     if (MODE == 1) tiled = tiled && ov_al16(s.x) && (s.xld % 4 == 0);
     if (MODE == 2) tiled = tiled && ov_al16(rec_out) && (rec_ld % 4 == 0);
     if (!tiled) return ov_dec_fwd_level<MODE>(s, d.C, d.C + d.G, rec_out, rec_ld);
-    dim3 grid((d.G + OV_GT_GENES - 1) / OV_GT_GENES, s.nchunk);
     const float* vals = c->P + c->lay.dec_vals;
     const float* bias = c->P + c->lay.dec_bias;
     OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_GENE, s.st);
+    if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
+        const int ncb = s.ldb / 32, ntiles = (d.G + 31) / 32;
+        hipLaunchKernelGGL((ov_gene_cb_kernel<MODE>), dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->rowptr, c->colidx, vals, bias,
+                           s.ws.act, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C, ncb, ntiles);
+        OV_LAUNCH_CHECK();
+        return ONTOVAE_OK;
+    }
+    dim3 grid((d.G + OV_GT_GENES - 1) / OV_GT_GENES, s.nchunk);
 #define OV_GT(V)                                                                                                       \
     hipLaunchKernelGGL((ov_dec_gene_tile_kernel<V, MODE>), grid, dim3(512), 0, s.st, c->rowptr, c->colidx, vals, bias, s.ws.act, \
                        s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C)
@@ -1461,6 +1708,7 @@ static int ov_dec_gene(OvStep& s, float* rec_out, int64_t rec_ld) {
 static int ov_nrec(const OvStep& s) {
     const ontovae_dims_t& d = s.c->dims;
     const bool tiled = (d.G % 4 == 0) && !(s.c->flags & ONTOVAE_FLAG_ROW_GENE_LAYER) && ov_al16(s.x) && (s.xld % 4 == 0);
+    if (tiled && !(s.c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) return ov_cb_grid(s.ldb / 32, (d.G + 31) / 32);
     return (tiled ? (d.G + OV_GT_GENES - 1) / OV_GT_GENES : (d.G + 3) / 4) * s.nchunk;
 }
 
@@ -1488,7 +1736,13 @@ static int ov_dec_backward(OvStep& s) {
         return ONTOVAE_OK;
     }
     const float* vals = c->P + c->lay.dec_vals;
-    {
+    if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
+        OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
+        const int ncb = s.ldb / 32, ntiles = (d.C + 7) / 8;
+        hipLaunchKernelGGL(ov_bwd_gene_cb_kernel, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row,
+                           c->csc_k, vals, s.ws.d, d.C, s.ldb, ncb, ntiles);
+        OV_LAUNCH_CHECK();
+    } else {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
         dim3 grid((d.C + 3) / 4, s.nchunk);
 #define OV_BG(V) hipLaunchKernelGGL((ov_dec_bwd_gene_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row, c->csc_k, vals, s.ws.d, d.C, s.ldb)
