@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libontovae_hip.so")
+LIB_PATH = os.environ.get("ONTOVAE_HIP_LIB") or os.path.join(HERE, "libontovae_hip.so")
 ABI_VERSION = 2
 
 c_i32p = C.POINTER(C.c_int32)

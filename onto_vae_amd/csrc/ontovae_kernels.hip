@@ -537,11 +537,31 @@ __global__ __launch_bounds__(256) void ov_dec_fwd_kernel(const int32_t* __restri
 // the gene layer and the weight gradient.
 // -------------------------------------------------------------------------------------------------
 #define OV_MAX_LEVELS 64
-struct OvLevels {
+// The chain as a flat list of steps that every wave walks: in step q a wave owns slice base[q] + wave if that
+// is below end[q]; a step that opens a new level is marked in bit 30 of base[q] (workgroup barrier first).
+#define OV_MAX_STEPS 240
+struct OvSteps {
     int n;
-    int first[OV_MAX_LEVELS];   // first slice of each level, in processing order
-    int count[OV_MAX_LEVELS];
+    int last_slice;            // n_slices - 1: where requests beyond the schedule are clamped to
+    int base[OV_MAX_STEPS];
+    int end[OV_MAX_STEPS];
 };
+#define OV_STEP_NEW_LEVEL (1 << 30)
+// false if the schedule does not fit (the caller then launches level by level)
+static bool ov_make_steps(const ontovae_sell_t& f, OvSteps* st) {
+    st->n = 0;
+    st->last_slice = std::max(f.n_slices - 1, 0);
+    for (int li = 0; li < f.n_levels; ++li) {
+        const int first = f.level_first[li], count = f.level_count[li];
+        for (int j = 0; 16 * j < count; ++j) {
+            if (st->n >= OV_MAX_STEPS) return false;
+            st->base[st->n] = (first + 16 * j) | ((j == 0 && st->n > 0) ? OV_STEP_NEW_LEVEL : 0);
+            st->end[st->n] = first + count;
+            ++st->n;
+        }
+    }
+    return true;
+}
 
 // sum over aligned groups of 2^LG lanes; the LAST lane of every group ends up with the group total
 template <int LG>
@@ -596,6 +616,18 @@ __global__ __launch_bounds__(256) void ov_sell_refresh_kernel(const float* __res
 // lanes that share a node, one store to LDS and one to the feature-major matrix in HBM.
 //   FWD: out = bias + sum w * panel[idx]      BWD: out = D (gene part, from HBM) + sum w * dpanel[idx]
 // -------------------------------------------------------------------------------------------------
+#ifdef OV_CHAIN_PROBE    // scratch/chain_probe.py: per-wave timestamps of the first 4 workgroups
+__device__ unsigned long long ov_chain_probe_buf[2 * 4 * 16 * 32];
+#define OV_CPROBE(slot) do { if (blockIdx.x < 4 && lane == 0 && (slot) < 32) ov_chain_probe_buf[(((BWD ? 4 : 0) + blockIdx.x) * 16 + wave) * 32 + (slot)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int ontovae_debug_chain_probe(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ov_chain_probe_buf), sizeof(ov_chain_probe_buf)) == hipSuccess ? 0 : -1;
+}
+#else
+#define OV_CPROBE(slot) do { } while (0)
+#endif
+#ifndef OV_CHAIN_DEPTH
+#define OV_CHAIN_DEPTH 3     // records in flight per wave (19 registers each; 16 waves per CU leave 128 per lane)
+#endif
 struct OvRec {          // chunk 0 of one lane of a slice
     int node, info;
     int id[8];
@@ -620,99 +652,118 @@ __device__ __forceinline__ void ov_rec_load(OvRec& r, int sl, int lane, const in
     r.bias = BWD ? 0.f : sbias[sl * 64 + lane];
 }
 
-template <int BT, bool BWD>
+template <int BT, bool BWD, bool SINGLE>
 __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __restrict__ snode, const int32_t* __restrict__ sinfo,
                                                           const int32_t* __restrict__ chunk0, const int32_t* __restrict__ sidx,
                                                           const float* __restrict__ sw, const float* __restrict__ sbias,
                                                           float* __restrict__ glob, int ldb, int in0, int in1, int out0, int out1,
-                                                          int single, const OvLevels lv, int dbg) {
+                                                          const OvSteps st, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float ov_panel[];
     const int b0 = blockIdx.x * BT;
     const int lane = ov_lane();
     const int wave = ov_wave_id();
+    OV_CPROBE(0);
 
-    // this wave's slice sequence: (level pl, slice psl), advanced one slice ahead of the one being computed
-    int pl = 0, psl = lv.n > 0 ? lv.first[0] + wave : 0;
-    while (pl < lv.n && psl >= lv.first[pl] + lv.count[pl]) {
-        ++pl;
-        if (pl < lv.n) psl = lv.first[pl] + wave;
-    }
-    OvRec nxt;
-    if (pl < lv.n) ov_rec_load<BWD>(nxt, psl, lane, snode, sinfo, chunk0, sidx, sw, sbias, single);
+    // Records are requested OV_CHAIN_DEPTH steps ahead, across level boundaries: a step's own work (a few LDS
+    // gathers) is far shorter than the memory round trip of its record.  Every request is unconditional (a
+    // wave without a slice in some step, or past the end of the schedule, re-reads a clamped slice) so that
+    // the number of loads between a request and its use is the same on every path and the waits stay exact.
+    auto request = [&](OvRec& r, int q) {
+        const int qq = min(q, st.n - 1);
+        const int sl = min(min((st.base[qq] & ~OV_STEP_NEW_LEVEL) + wave, st.end[qq] - 1), st.last_slice);
+        ov_rec_load<BWD>(r, sl, lane, snode, sinfo, chunk0, sidx, sw, sbias, SINGLE ? 1 : 0);
+    };
+    OvRec rec[OV_CHAIN_DEPTH];
+#pragma unroll
+    for (int t = 0; t < OV_CHAIN_DEPTH; ++t) request(rec[t], t);
 
     // prologue: the rows the chain starts from, HBM -> LDS.  FWD: level 0 (z).  BWD: every panel row
-    // (the gene layer's contribution, written by ov_dec_bwd_gene_kernel).
-    for (int p = in0 + threadIdx.x; p < in1; p += 4096) {
-        float v[4][BT];
+    // (the gene layer's contribution, written by the gene backward kernel).
+    for (int p = in0 + threadIdx.x; p < in1; p += 8 * 1024) {
+        float v[8][BT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
             if (p + u * 1024 < in1) ov_ldv<BT>(glob + (int64_t)(p + u * 1024) * ldb + b0, v[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
             if (p + u * 1024 < in1) ov_stv<BT>(ov_panel + (int64_t)(p + u * 1024) * BT, v[u]);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    OV_CPROBE(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    OV_CPROBE(2);
 
-    for (int li = 0; li < ((dbg & 2) ? 0 : lv.n); ++li) {
-        const int s_end = lv.first[li] + lv.count[li];
-        for (int sl = lv.first[li] + wave; sl < s_end; sl += 16) {
-            const OvRec cur = nxt;
-            psl += 16;
-            while (pl < lv.n && psl >= lv.first[pl] + lv.count[pl]) {
-                ++pl;
-                if (pl < lv.n) psl = lv.first[pl] + wave;
-            }
-            if (pl < lv.n) ov_rec_load<BWD>(nxt, psl, lane, snode, sinfo, chunk0, sidx, sw, sbias, single);
-
-            const int cnt = cur.info & 0xFFFF;
-            const int lg = __builtin_amdgcn_readfirstlane((cur.info >> 16) & 7);
-            const bool writer = (cur.info >> 24) & 1;
-            float acc[BT];
+    for (int q0 = 0; q0 < st.n; q0 += OV_CHAIN_DEPTH) {
 #pragma unroll
-            for (int j = 0; j < BT; ++j) acc[j] = 0.f;
-            {
-                float v[8][BT];
+        for (int t = 0; t < OV_CHAIN_DEPTH; ++t) {
+            const int q = q0 + t;
+            if (q < st.n) {                          // uniform over the workgroup
+                const int bq = st.base[q];
+                if ((bq & OV_STEP_NEW_LEVEL) && !(dbg & 4)) {
+                    // LDS writes of the level must land before the next level reads them
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    OV_CPROBE(3 + (q < 28 ? q : 28));
+                }
+                const int sl = (bq & ~OV_STEP_NEW_LEVEL) + wave;
+                if (sl < st.end[q] && !(dbg & 2)) {                // uniform over the wave
+                    const OvRec& cur = rec[t];
+                    const int cnt = cur.info & 0xFFFF;
+                    const int lg = __builtin_amdgcn_readfirstlane((cur.info >> 16) & 7);
+                    const int width = __builtin_amdgcn_readfirstlane((cur.info >> 20) & 15);   // entries per lane of this slice
+                    const bool writer = (cur.info >> 24) & 1;
+                    float acc[BT];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ov_ldv<BT>(ov_panel + (int64_t)cur.id[e] * BT, v[e]);
+                    for (int j = 0; j < BT; ++j) acc[j] = 0.f;
+                    {
+                        // padding slots have weight 0 and point at a row this slice really reads: plain FMAs
+                        float v[8][BT];
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
+                        for (int e = 0; e < 8; ++e)
+                            if (e < width) ov_ldv<BT>(ov_panel + (int64_t)cur.id[e] * BT, v[e]);
 #pragma unroll
-                    for (int j = 0; j < BT; ++j) acc[j] += e < cnt ? cur.w[e] * v[e][j] : 0.f;   // padding never enters the sum
-            }
-            if (!single) {          // lanes with more than 8 entries: further chunks, loaded on demand
-                const int c0 = chunk0[sl], R = chunk0[sl + 1] - c0;
-                for (int r = 1; r < R; ++r) {
-                    const int base = (c0 + r) * 512 + lane;
-                    const int rem = cnt - r * 8;
+                        for (int e = 0; e < 8; ++e)
+                            if (e < width) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float v0[BT];
-                        const float w0 = sw[base + e * 64];
-                        ov_ldv<BT>(ov_panel + (int64_t)sidx[base + e * 64] * BT, v0);
+                                for (int j = 0; j < BT; ++j) acc[j] += cur.w[e] * v[e][j];
+                            }
+                    }
+                    if (!SINGLE) {          // lanes with more than 8 entries: further chunks, loaded on demand
+                        const int c0 = chunk0[sl], R = chunk0[sl + 1] - c0;
+                        for (int r = 1; r < R; ++r) {
+                            const int base = (c0 + r) * 512 + lane;
+                            const int rem = cnt - r * 8;
 #pragma unroll
-                        for (int j = 0; j < BT; ++j) acc[j] += e < rem ? w0 * v0[j] : 0.f;
+                            for (int e = 0; e < 8; ++e) {
+                                float v0[BT];
+                                const float w0 = sw[base + e * 64];
+                                ov_ldv<BT>(ov_panel + (int64_t)sidx[base + e * 64] * BT, v0);
+#pragma unroll
+                                for (int j = 0; j < BT; ++j) acc[j] += e < rem ? w0 * v0[j] : 0.f;
+                            }
+                        }
+                    }
+                    ov_group_sum_rt<BT>(acc, lg);
+                    if (writer) {
+                        if (BWD) {
+                            float g0[BT];
+                            ov_ldv<BT>(ov_panel + (int64_t)cur.node * BT, g0);
+#pragma unroll
+                            for (int j = 0; j < BT; ++j) acc[j] += g0[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < BT; ++j) acc[j] += cur.bias;
+                        }
+                        ov_stv<BT>(ov_panel + (int64_t)cur.node * BT, acc);
                     }
                 }
-            }
-            ov_group_sum_rt<BT>(acc, lg);
-            if (writer) {
-                if (BWD) {
-                    float g0[BT];
-                    ov_ldv<BT>(ov_panel + (int64_t)cur.node * BT, g0);
-#pragma unroll
-                    for (int j = 0; j < BT; ++j) acc[j] += g0[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < BT; ++j) acc[j] += cur.bias;
-                }
-                ov_stv<BT>(ov_panel + (int64_t)cur.node * BT, acc);
+                if (!(dbg & 1)) request(rec[t], q + OV_CHAIN_DEPTH);     // this ring slot's next record
             }
         }
-        // LDS writes must land before the next level reads them (no HBM traffic inside the chain)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    OV_CPROBE(30);
 
     // epilogue: results LDS -> HBM (feature-major), for the gene layer and the weight gradient
     if (!(dbg & 1))
@@ -721,6 +772,7 @@ __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __res
         ov_ldv<BT>(ov_panel + (int64_t)p * BT, v);
         ov_stv<BT>(glob + (int64_t)p * ldb + b0, v);
     }
+    OV_CPROBE(31);
 }
 
 // Cooperative entry prefetch for the row-per-wave gather kernels: the 64 lanes load up to 64
@@ -882,6 +934,12 @@ __global__ __launch_bounds__(512) void ov_dec_gene_tile_kernel(const int32_t* __
 // puts the entry of group grp at step i into lane (grp, i): a ds_swizzle broadcast within the group
 // hands it out.  The 8 group partials are summed at the end (swizzle xor 8, 16, bpermute xor 32).
 // =================================================================================================
+#ifndef OV_GENE_FWD_U
+#define OV_GENE_FWD_U 1     // batches of 8 entries per lane group in flight, forward (lists of ~24)
+#endif
+#ifndef OV_GENE_BWD_U
+#define OV_GENE_BWD_U 1     // backward (lists of ~55)
+#endif
 struct OvCbMap { int cb, tile; };
 // workgroup id -> (column block, row tile); ncb is 1, 2, 4, 8 or a multiple of 8
 __device__ __forceinline__ OvCbMap ov_cb_map(int id, int ncb) {
@@ -952,7 +1010,7 @@ __device__ __forceinline__ void ov_gather_cb(f32x4& acc, int k0, int k1, const i
 // are per group.  Batches of 8 entries per group: the group's 8 lanes load 8 consecutive (index, weight) pairs, the
 // next batch is requested before the current one's row gathers, and a ds_swizzle broadcast within the group hands
 // entry i to all 8 lanes.  Groups whose list is shorter than the wave's longest re-read their last row with weight 0.
-template <bool INDIRECT>
+template <bool INDIRECT, int U>
 __device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const int32_t* __restrict__ rowidx,
                                               const int32_t* __restrict__ kidx, const float* __restrict__ vals,
                                               const float* __restrict__ srccol, int ldb, int lane) {
@@ -968,27 +1026,62 @@ __device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const
         w = 0.f;
         if (e < len) w = INDIRECT ? vals[kidx[k0 + e]] : vals[k0 + e];
     };
-    int cur_r, nxt_r = 0;
-    float cur_w, nxt_w = 0.f;
-    fetch(s, cur_r, cur_w);
-    for (int b0 = 0; b0 < maxlen; b0 += 8) {
-        if (b0 + 8 < maxlen) fetch(b0 + 8 + s, nxt_r, nxt_w);
-        f32x4 v[8];
-        float w[8];
+    int cur_r[U], nxt_r[U];
+    float cur_w[U], nxt_w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { fetch(8 * u + s, cur_r[u], cur_w[u]); nxt_r[u] = 0; nxt_w[u] = 0.f; }
+    for (int b0 = 0; b0 < maxlen; b0 += 8 * U) {
+        if (b0 + 8 * U < maxlen) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) fetch(b0 + 8 * U + 8 * u + s, nxt_r[u], nxt_w[u]);
+        }
+        f32x4 v[U][8];
+        float w[U][8];
 #define OV_GRP_STEP(I)                                                                                    \
         {                                                                                                 \
-            const int r = ov_grp_bcast<I>(cur_r);                                                         \
-            w[I] = ov_grp_bcast<I>(cur_w);                                                                \
-            v[I] = *reinterpret_cast<const f32x4*>(srccol + (int64_t)r * ldb);                            \
+            const int r = ov_grp_bcast<I>(cur_r[u]);                                                      \
+            w[u][I] = ov_grp_bcast<I>(cur_w[u]);                                                          \
+            v[u][I] = *reinterpret_cast<const f32x4*>(srccol + (int64_t)r * ldb);                         \
         }
-        OV_GRP_STEP(0) OV_GRP_STEP(1) OV_GRP_STEP(2) OV_GRP_STEP(3) OV_GRP_STEP(4) OV_GRP_STEP(5) OV_GRP_STEP(6) OV_GRP_STEP(7)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u == 0 || b0 + 8 * u < maxlen) {
+                OV_GRP_STEP(0) OV_GRP_STEP(1) OV_GRP_STEP(2) OV_GRP_STEP(3) OV_GRP_STEP(4) OV_GRP_STEP(5) OV_GRP_STEP(6) OV_GRP_STEP(7)
+            }
+        }
 #undef OV_GRP_STEP
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            acc.x += w[i] * v[i].x; acc.y += w[i] * v[i].y; acc.z += w[i] * v[i].z; acc.w += w[i] * v[i].w;
+        for (int u = 0; u < U; ++u) {
+            if (u == 0 || b0 + 8 * u < maxlen) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc.x += w[u][i] * v[u][i].x; acc.y += w[u][i] * v[u][i].y;
+                    acc.z += w[u][i] * v[u][i].z; acc.w += w[u][i] * v[u][i].w;
+                }
+            }
         }
-        cur_r = nxt_r; cur_w = nxt_w;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { cur_r[u] = nxt_r[u]; cur_w[u] = nxt_w[u]; }
     }
+}
+
+// The 32 rows of a tile are dealt to the lane groups in order of decreasing list length (rank by counting in
+// LDS), so that the 8 groups of a wave walk lists of similar length.  Call with all 256 threads; returns the
+// tile-local row of this thread's group and its list (k0, len).
+__device__ __forceinline__ int ov_tile_balance(int my_k0, int my_len, int* sh_k0, int* sh_len, int* sh_ord, int& k0, int& len) {
+    const int tid = threadIdx.x;
+    if (tid < 32) { sh_k0[tid] = my_k0; sh_len[tid] = my_len; }
+    __syncthreads();
+    if (tid < 32) {
+        int rank = 0;
+        for (int j = 0; j < 32; ++j) rank += (sh_len[j] > my_len || (sh_len[j] == my_len && j < tid)) ? 1 : 0;
+        sh_ord[rank] = tid;
+    }
+    __syncthreads();
+    const int row = sh_ord[tid >> 3];
+    k0 = sh_k0[row];
+    len = sh_len[row];
+    return row;
 }
 
 // Gene layer forward on a (32 genes) x (32 columns) tile: 4 waves, one gene per lane group (8 genes per wave).
@@ -1004,6 +1097,7 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
     constexpr int TG = 32, LD = 33;
     __shared__ float xs[TG * LD];
     __shared__ float red[4];
+    __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
     const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
     if (map.tile >= ntiles) {                      // workgroup-uniform
         if (MODE == 1 && threadIdx.x == 0) rec_part[blockIdx.x] = 0.f;
@@ -1014,12 +1108,13 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
     const int wave = ov_wave_id();
     const int tid = threadIdx.x;
     const int s4 = 4 * (lane & 7);
-    const int gl = 8 * wave + (lane >> 3);
+    // the lists first: everything else waits on them
+    int my_k0 = 0, my_len = 0;
+    if (tid < 32 && g0 + tid < G) { my_k0 = rowptr[C + g0 + tid]; my_len = rowptr[C + g0 + tid + 1] - my_k0; }
+    int k0, len;
+    const int gl = ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
     const int g = g0 + gl;
     const int node = C + min(g, G - 1);
-    // the group's list first: everything else waits on it
-    const int k0 = rowptr[node];
-    const int len = g < G ? rowptr[node + 1] - k0 : 0;
     if (MODE == 1) {
         const int b = tid >> 3, j = tid & 7;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -1034,7 +1129,7 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
     }
     const float bv = bias[node];
     f32x4 acc = {bv, bv, bv, bv};
-    ov_gather_grp<false>(acc, k0, len, colidx, nullptr, vals, act + col0 + s4, ldb, lane);
+    ov_gather_grp<false, OV_GENE_FWD_U>(acc, k0, len, colidx, nullptr, vals, act + col0 + s4, ldb, lane);
     if (MODE == 1) {
         __syncthreads();
         float sq = 0.f;
@@ -1072,31 +1167,26 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
 }
 
 // Gene part of the backward on 32-column blocks: D[p, cols] = sum over the genes g of column p of W[g, p] * D[g, cols].
-// 4 waves, 2 panel nodes per wave.
+// 4 waves, 32 panel nodes per workgroup, one node per lane group.
 __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_split,
                                                             const int32_t* __restrict__ csc_row, const int32_t* __restrict__ csc_k,
                                                             const float* __restrict__ vals, float* __restrict__ d, int C, int ldb,
                                                             int ncb, int ntiles) {
+    __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
     const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
     if (map.tile >= ntiles) return;
     const int lane = ov_lane();
     const int col0 = map.cb * 32, s4 = 4 * (lane & 7);
-    const float* dcol = d + col0 + s4;
-#pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-        const int node = map.tile * 8 + ov_wave_id() * 2 + t;
-        if (node >= C) return;
-        const int k0 = __builtin_amdgcn_readfirstlane(csc_split[node]);
-        const int k1 = __builtin_amdgcn_readfirstlane(cscptr[node + 1]);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        ov_gather_cb<true>(acc, k0, k1, csc_row, csc_k, vals, dcol, ldb, lane);
-        f32x4 o;
-        o.x = ov_grp_reduce(acc.x, lane);
-        o.y = ov_grp_reduce(acc.y, lane);
-        o.z = ov_grp_reduce(acc.z, lane);
-        o.w = ov_grp_reduce(acc.w, lane);
-        if (lane < 8) *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = o;
+    int my_k0 = 0, my_len = 0;
+    if (threadIdx.x < 32) {
+        const int node = map.tile * 32 + threadIdx.x;
+        if (node < C) { my_k0 = csc_split[node]; my_len = cscptr[node + 1] - my_k0; }
     }
+    int k0, len;
+    const int node = map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    ov_gather_grp<true, OV_GENE_BWD_U>(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane);
+    if (node < C) *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = acc;
 }
 
 // Backward data, one wave per (panel node of the level, batch chunk), CSC gather:
@@ -1617,6 +1707,8 @@ static int ov_fused_bt(const ontovae_ctx_t* c) {
         !f.idx || !f.k || !f.w || !f.bias || !b.node || !b.info || !b.chunk0 || !b.idx || !b.k || !b.w || !f.level_first ||
         !f.level_count || !b.level_first || !b.level_count)
         return 0;
+    OvSteps tmp;
+    if (!ov_make_steps(f, &tmp) || !ov_make_steps(b, &tmp)) return 0;
     const int64_t lds = 160 * 1024;
     if ((int64_t)d.C * 16 <= lds) return 4;
     if ((int64_t)d.C * 8 <= lds) return 2;
@@ -1660,17 +1752,18 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     int rc;
     if (!refreshed && (rc = ov_sell_refresh(s, s.st))) return rc;
     const ontovae_sell_t& f = c->sell_fwd;
-    OvLevels lv;
-    lv.n = f.n_levels;
-    for (int i = 0; i < lv.n; ++i) { lv.first[i] = f.level_first[i]; lv.count[i] = f.level_count[i]; }
+    OvSteps lv;
+    ov_make_steps(f, &lv);
     const size_t lds = (size_t)d.C * bt * sizeof(float);
     OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
-#define OV_TF(BT)                                                                                                     \
-    if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false>, lds))) return rc;                                             \
-    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false>), dim3(s.ldb / BT), dim3(1024), lds, s.st, f.node, f.info, f.chunk0, \
-                       f.idx, f.w, f.bias, s.ws.act, s.ldb, d.C - d.L, d.C, 0, d.C - d.L, f.all_single_chunk, lv, (int)(c->flags >> 8))
+#define OV_TF2(BT, SG)                                                                                                \
+    if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false, SG>, lds))) return rc;                                         \
+    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, f.node, f.info, f.chunk0, \
+                       f.idx, f.w, f.bias, s.ws.act, s.ldb, d.C - d.L, d.C, 0, d.C - d.L, lv, (int)(c->flags >> 8))
+#define OV_TF(BT) do { if (f.all_single_chunk) { OV_TF2(BT, true); } else { OV_TF2(BT, false); } } while (0)
     if (bt == 4) { OV_TF(4); } else if (bt == 2) { OV_TF(2); } else { OV_TF(1); }
 #undef OV_TF
+#undef OV_TF2
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
@@ -1738,7 +1831,7 @@ static int ov_dec_backward(OvStep& s) {
     const float* vals = c->P + c->lay.dec_vals;
     if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
-        const int ncb = s.ldb / 32, ntiles = (d.C + 7) / 8;
+        const int ncb = s.ldb / 32, ntiles = (d.C + 31) / 32;
         hipLaunchKernelGGL(ov_bwd_gene_cb_kernel, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row,
                            c->csc_k, vals, s.ws.d, d.C, s.ldb, ncb, ntiles);
         OV_LAUNCH_CHECK();
@@ -1751,17 +1844,18 @@ static int ov_dec_backward(OvStep& s) {
         OV_LAUNCH_CHECK();
     }
     const ontovae_sell_t& sb = c->sell_bwd;
-    OvLevels lv;
-    lv.n = sb.n_levels;
-    for (int i = 0; i < lv.n; ++i) { lv.first[i] = sb.level_first[i]; lv.count[i] = sb.level_count[i]; }
+    OvSteps lv;
+    ov_make_steps(sb, &lv);
     const size_t lds = (size_t)d.C * bt * sizeof(float);
     OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
-#define OV_TB(BT)                                                                                                     \
-    if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true>, lds))) return rc;                                              \
-    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true>), dim3(s.ldb / BT), dim3(1024), lds, s.st, sb.node, sb.info, sb.chunk0, \
-                       sb.idx, sb.w, (const float*)nullptr, s.ws.d, s.ldb, 0, d.C, 0, d.C, sb.all_single_chunk, lv, (int)(c->flags >> 8))
+#define OV_TB2(BT, SG)                                                                                                \
+    if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true, SG>, lds))) return rc;                                          \
+    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, sb.node, sb.info, sb.chunk0, \
+                       sb.idx, sb.w, (const float*)nullptr, s.ws.d, s.ldb, 0, d.C, 0, d.C, lv, (int)(c->flags >> 8))
+#define OV_TB(BT) do { if (sb.all_single_chunk) { OV_TB2(BT, true); } else { OV_TB2(BT, false); } } while (0)
     if (bt == 4) { OV_TB(4); } else if (bt == 2) { OV_TB(2); } else { OV_TB(1); }
 #undef OV_TB
+#undef OV_TB2
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }

@@ -77,27 +77,43 @@ static void build_sell(ontovae_plan* p, int dir) {
             if (R > 1) S.all_single = 0;
             int lg = 0;
             while ((1 << lg) < g) ++lg;
+            // entries per lane: an even split over the g lanes when one chunk is enough (W <= 8 is the slice's
+            // width: the kernel gathers W entries per lane, not 8), else R chunks of 8 per lane
+            const int32_t W = R == 1 ? (len0 + g - 1) / g : 8;
+            const int32_t per_lane = R == 1 ? W : R * 8;
             const size_t lane0 = S.node.size();
             S.node.resize(lane0 + 64, -1);
-            S.info.resize(lane0 + 64, lg << 16);
+            S.info.resize(lane0 + 64, (lg << 16) | (W << 20));
             const size_t e0 = S.idx.size();
-            S.idx.resize(e0 + (size_t)R * 512, 0);
+            S.idx.resize(e0 + (size_t)R * 512, -1);
             S.k.resize(e0 + (size_t)R * 512, -1);
+            int32_t slice_pad = -1;                                          // a row this slice really reads
             for (int slot = 0; slot < 64 / g && i < nodes.size(); ++slot, ++i) {
                 const int32_t len = nodes[i].first, n = nodes[i].second;
                 const int32_t base = lo(n);
                 for (int gl = 0; gl < g; ++gl) {
                     const int lane = slot * g + gl;
-                    const int32_t first = gl * R * 8;                       // this lane's entries: [first, first + R*8)
-                    const int32_t cnt = std::max<int32_t>(0, std::min<int32_t>(len - first, R * 8));
+                    const int32_t first = gl * per_lane;                    // this lane's entries: [first, first + per_lane)
+                    const int32_t cnt = std::max<int32_t>(0, std::min<int32_t>(len - first, per_lane));
                     S.node[lane0 + lane] = n;
-                    S.info[lane0 + lane] = cnt | (lg << 16) | ((gl == g - 1) ? (1 << 24) : 0);
+                    S.info[lane0 + lane] = cnt | (lg << 16) | (W << 20) | ((gl == g - 1) ? (1 << 24) : 0);
                     for (int32_t e = 0; e < cnt; ++e) {
                         const int32_t q = base + first + e;
                         const size_t pos = e0 + (size_t)(e / 8) * 512 + (size_t)(e % 8) * 64 + lane;
                         S.idx[pos] = dir == 0 ? p->colidx[q] : p->csc_row[q];
                         S.k[pos] = dir == 0 ? q : p->csc_k[q];
+                        if (slice_pad < 0) slice_pad = S.idx[pos];
                     }
+                }
+            }
+            // padding slots carry weight 0 (k = -1) and the index of a row that is valid input of this slice:
+            // the lane's own first entry, else the slice's first, so that 0 * value never meets unwritten memory
+            for (int lane = 0; lane < 64; ++lane) {
+                const int32_t own = S.idx[e0 + lane];
+                const int32_t pad = own >= 0 ? own : std::max<int32_t>(slice_pad, 0);
+                for (int32_t e = 0; e < R * 8; ++e) {
+                    const size_t pos = e0 + (size_t)(e / 8) * 512 + (size_t)(e % 8) * 64 + lane;
+                    if (S.k[pos] < 0) S.idx[pos] = pad;
                 }
             }
             nchunks += R;

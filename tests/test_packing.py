@@ -116,6 +116,12 @@ def check_sell(plan):
                 lg = (info >> 16) & 7
                 assert len(set(lg.tolist())) == 1
                 g = 1 << int(lg[0])
+                width = (info >> 20) & 15
+                assert len(set(width.tolist())) == 1
+                W = int(width[0])
+                assert W <= 8 and (c1 - c0 == 1 or W == 8)
+                # rows a slice may read: the levels before it in processing order
+                ok_row = (lambda r: r >= plan.level_end[d]) if direction == 0 else (lambda r: r < plan.level_begin[d])
                 for lane in range(64):
                     n = int(node[lane])
                     cnt = int(info[lane] & 0xFFFF)
@@ -125,7 +131,11 @@ def check_sell(plan):
                         continue
                     assert writer == (lane % g == g - 1)
                     assert cnt <= (c1 - c0) * 8
+                    assert c1 - c0 > 1 or cnt <= W
                     got_nodes.add(n)
+                    for e in range(cnt, W):                       # padding inside the width: weight 0, a readable row
+                        pos = c0 * 512 + e * 64 + lane
+                        assert int(sd["k"][pos]) == -1 and ok_row(int(sd["idx"][pos]))
                     for e in range(cnt):
                         pos = (c0 + e // 8) * 512 + (e % 8) * 64 + lane
                         seen.setdefault(n, []).append((int(sd["idx"][pos]), int(sd["k"][pos])))
