@@ -100,7 +100,7 @@ static inline int ov_ldb(int B) { const int q = 64 * ov_vec(B); return (B + q - 
 // Workspace
 // =================================================================================================
 struct OvWs {
-    float *slab, *xhat, *a, *mulv, *epsw, *act, *d, *dmulv, *da, *dh;
+    float *slab, *xhat, *a, *mulv, *epsw, *act, *d, *dblk, *dmulv, *da, *dh;
     float *bn_mean, *bn_invstd, *bn_bwd_local;
     float *rec_part, *kl_part;
     int64_t slab_floats;
@@ -138,6 +138,7 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs
     w.epsw = take(L * ldb);
     w.act = take(C * ldb);
     w.d = take((C + G) * ldb);
+    w.dblk = take(C * ldb);      // panel rows of D in column-group-major order [ldb / 4][C][4] (backward chain input)
     w.dmulv = take(2 * L * ldb);
     w.da = take(L * ldb);
     w.dh = take(L * ldb);
@@ -656,8 +657,8 @@ template <int BT, bool BWD, bool SINGLE>
 __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __restrict__ snode, const int32_t* __restrict__ sinfo,
                                                           const int32_t* __restrict__ chunk0, const int32_t* __restrict__ sidx,
                                                           const float* __restrict__ sw, const float* __restrict__ sbias,
-                                                          float* __restrict__ glob, int ldb, int in0, int in1, int out0, int out1,
-                                                          const OvSteps st, int dbg) {
+                                                          float* __restrict__ glob, const float* __restrict__ inblk, int ldb,
+                                                          int in0, int in1, int out0, int out1, const OvSteps st, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float ov_panel[];
     const int b0 = blockIdx.x * BT;
     const int lane = ov_lane();
@@ -679,11 +680,14 @@ __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __res
 
     // prologue: the rows the chain starts from, HBM -> LDS.  FWD: level 0 (z).  BWD: every panel row
     // (the gene layer's contribution, written by the gene backward kernel).
+    // inblk (BT == 4 only): the same rows in column-group-major order, one contiguous piece per workgroup
+    const float* src = (BT == 4 && inblk) ? inblk + (int64_t)blockIdx.x * out1 * 4 : glob + b0;
+    const int64_t src_ld = (BT == 4 && inblk) ? 4 : ldb;
     for (int p = in0 + threadIdx.x; p < in1; p += 8 * 1024) {
         float v[8][BT];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (p + u * 1024 < in1) ov_ldv<BT>(glob + (int64_t)(p + u * 1024) * ldb + b0, v[u]);
+            if (p + u * 1024 < in1) ov_ldv<BT>(src + (int64_t)(p + u * 1024) * src_ld, v[u]);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (p + u * 1024 < in1) ov_stv<BT>(ov_panel + (int64_t)(p + u * 1024) * BT, v[u]);
@@ -1170,8 +1174,8 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
 // 4 waves, 32 panel nodes per workgroup, one node per lane group.
 __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_split,
                                                             const int32_t* __restrict__ csc_row, const int32_t* __restrict__ csc_k,
-                                                            const float* __restrict__ vals, float* __restrict__ d, int C, int ldb,
-                                                            int ncb, int ntiles) {
+                                                            const float* __restrict__ vals, float* __restrict__ d,
+                                                            float* __restrict__ dblk, int C, int ldb, int ncb, int ntiles) {
     __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
     const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
     if (map.tile >= ntiles) return;
@@ -1186,7 +1190,11 @@ __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __re
     const int node = map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     ov_gather_grp<true, OV_GENE_BWD_U>(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane);
-    if (node < C) *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = acc;
+    if (node < C) {
+        // dblk: column-group-major [ldb / 4][C][4], what a workgroup of the backward chain loads in one piece
+        if (dblk) *reinterpret_cast<f32x4*>(dblk + ((int64_t)(map.cb * 8 + (lane & 7)) * C + node) * 4) = acc;
+        else *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = acc;
+    }
 }
 
 // Backward data, one wave per (panel node of the level, batch chunk), CSC gather:
@@ -1759,7 +1767,7 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
 #define OV_TF2(BT, SG)                                                                                                \
     if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false, SG>, lds))) return rc;                                         \
     hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, f.node, f.info, f.chunk0, \
-                       f.idx, f.w, f.bias, s.ws.act, s.ldb, d.C - d.L, d.C, 0, d.C - d.L, lv, (int)(c->flags >> 8))
+                       f.idx, f.w, f.bias, s.ws.act, (const float*)nullptr, s.ldb, d.C - d.L, d.C, 0, d.C - d.L, lv, (int)(c->flags >> 8))
 #define OV_TF(BT) do { if (f.all_single_chunk) { OV_TF2(BT, true); } else { OV_TF2(BT, false); } } while (0)
     if (bt == 4) { OV_TF(4); } else if (bt == 2) { OV_TF(2); } else { OV_TF(1); }
 #undef OV_TF
@@ -1829,11 +1837,13 @@ static int ov_dec_backward(OvStep& s) {
         return ONTOVAE_OK;
     }
     const float* vals = c->P + c->lay.dec_vals;
+    float* blk = nullptr;
     if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
         const int ncb = s.ldb / 32, ntiles = (d.C + 31) / 32;
+        if (bt == 4) blk = s.ws.dblk;           // the chain's workgroups take 4 columns each: hand them contiguous pieces
         hipLaunchKernelGGL(ov_bwd_gene_cb_kernel, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row,
-                           c->csc_k, vals, s.ws.d, d.C, s.ldb, ncb, ntiles);
+                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles);
         OV_LAUNCH_CHECK();
     } else {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
@@ -1851,7 +1861,7 @@ static int ov_dec_backward(OvStep& s) {
 #define OV_TB2(BT, SG)                                                                                                \
     if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true, SG>, lds))) return rc;                                          \
     hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, sb.node, sb.info, sb.chunk0, \
-                       sb.idx, sb.w, (const float*)nullptr, s.ws.d, s.ldb, 0, d.C, 0, d.C, lv, (int)(c->flags >> 8))
+                       sb.idx, sb.w, (const float*)nullptr, s.ws.d, (const float*)blk, s.ldb, 0, d.C, 0, d.C, lv, (int)(c->flags >> 8))
 #define OV_TB(BT) do { if (sb.all_single_chunk) { OV_TB2(BT, true); } else { OV_TB2(BT, false); } } while (0)
     if (bt == 4) { OV_TB(4); } else if (bt == 2) { OV_TB(2); } else { OV_TB(1); }
 #undef OV_TB
