@@ -103,6 +103,7 @@ struct OvWs {
     float *slab, *xhat, *a, *mulv, *epsw, *act, *d, *dblk, *dmulv, *da, *dh;
     float *bn_mean, *bn_invstd, *bn_bwd_local;
     float *rec_part, *kl_part;
+    float *wpart;              // [ldb / 32][nnz + C + G] weight-gradient partials of the 32-column blocks
     int64_t slab_floats;
     int npart_max;
 };
@@ -147,6 +148,7 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs
     w.bn_bwd_local = take(2 * L);
     w.rec_part = take(npart);
     w.kl_part = take(npart);
+    w.wpart = take((ldb / 32) * ((int64_t)d.nnz + C + G));
     w.slab_floats = slab;
     w.npart_max = (int)npart;
     if (ws) *ws = w;
@@ -1238,6 +1240,101 @@ __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restri
     ov_stv<VEC>(d + (int64_t)node * ldb + b0, acc);
 }
 
+// Weight gradient at mask positions (SDDMM) on 32-column blocks, one row per lane group:
+//   part[cb][k] = sum over the block's columns of D[n, b] * ACT[colidx[k], b]        bpart[cb][r] = sum of D[n, b]
+// The group's 8 lanes hold 4 columns each of D[n] in registers, gather the same 4 columns of ACT[p] (one 128-B
+// line per group), and a dot needs 3 DPP adds within the group instead of a wave-wide reduction.  The column
+// blocks are pinned to XCDs like the other gene-layer kernels, so the panel columns a workgroup gathers stay in its
+// L2.  ov_wgrad_finish_kernel adds the blocks' partials in a fixed order and applies AdamW + clamp.
+__global__ __launch_bounds__(256) void ov_wgrad_cb_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                         const float* __restrict__ act, const float* __restrict__ d,
+                                                         float* __restrict__ part, float* __restrict__ bpart, int64_t nnz, int nrows,
+                                                         int first_term_node, int n_term_rows, int C, int ldb, int ncb, int ntiles) {
+    __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
+    const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
+    if (map.tile >= ntiles) return;
+    const int lane = ov_lane();
+    const int s = lane & 7;
+    const int col0 = map.cb * 32, s4 = 4 * s;
+    auto node_of = [&](int r) { return r < n_term_rows ? first_term_node + r : C + (r - n_term_rows); };
+    int my_k0 = 0, my_len = 0;
+    if (threadIdx.x < 32) {
+        const int r = map.tile * 32 + threadIdx.x;
+        if (r < nrows) { const int n = node_of(r); my_k0 = rowptr[n]; my_len = rowptr[n + 1] - my_k0; }
+    }
+    int k0, len;
+    const int r = map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
+    const bool row_on = r < nrows;
+    const int node = node_of(min(r, nrows - 1));
+    const f32x4 dseg = *reinterpret_cast<const f32x4*>(d + (int64_t)node * ldb + col0 + s4);
+    {
+        float gb = (dseg.x + dseg.y) + (dseg.z + dseg.w);
+        gb = ov_group_sum<3>(gb);
+        if (row_on && s == 7) bpart[(int64_t)map.cb * nrows + r] = gb;
+    }
+    int maxlen = len;                                // wave maximum
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    const float* actcol = act + col0 + s4;
+    float* prow = part + (int64_t)map.cb * nnz + k0;
+    auto fetch = [&](int e) { return len > 0 ? colidx[k0 + max(min(e, len - 1), 0)] : 0; };
+    int cur_c = fetch(s), nxt_c = 0;
+    for (int b0 = 0; b0 < maxlen; b0 += 8) {
+        if (b0 + 8 < maxlen) nxt_c = fetch(b0 + 8 + s);
+        f32x4 v[8];
+#define OV_WG_LOAD(I) v[I] = *reinterpret_cast<const f32x4*>(actcol + (int64_t)ov_grp_bcast<I>(cur_c) * ldb);
+        OV_WG_LOAD(0) OV_WG_LOAD(1) OV_WG_LOAD(2) OV_WG_LOAD(3) OV_WG_LOAD(4) OV_WG_LOAD(5) OV_WG_LOAD(6) OV_WG_LOAD(7)
+#undef OV_WG_LOAD
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = dseg.x * v[i].x;
+            t += dseg.y * v[i].y;
+            t += dseg.z * v[i].z;
+            t += dseg.w * v[i].w;
+            t = ov_group_sum<3>(t);                                   // xor 1, xor 2, half mirror: every lane of the group has the total
+            mine = s == i ? t : mine;
+        }
+        if (row_on && b0 + s < len) prow[b0 + s] = mine;
+        cur_c = nxt_c;
+    }
+}
+
+// g_k = sum over column blocks of part[cb][k] (fixed order), then AdamW + clamp(0) (vae_model.py:172-176) or the
+// plain gradient; the same for the biases of the rows.
+__global__ __launch_bounds__(256) void ov_wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int ncb,
+                                                             int64_t k_begin, int64_t k_end, int64_t nnz, int nrows,
+                                                             int first_term_node, int n_term_rows, int C,
+                                                             float* __restrict__ vals, float* __restrict__ mvals, float* __restrict__ vvals,
+                                                             float* __restrict__ gvals, float* __restrict__ bias, float* __restrict__ mbias,
+                                                             float* __restrict__ vbias, float* __restrict__ gbias, int apply_update, OvAdam adam) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t k = k_begin + (int64_t)blockIdx.x * 256 + threadIdx.x; k < k_end; k += stride) {
+        float g = 0.f;
+        for (int cb = 0; cb < ncb; ++cb) g += part[(int64_t)cb * nnz + k];
+        if (apply_update) {
+            float w = vals[k], m = mvals[k], v = vvals[k];
+            ov_adamw(w, m, v, g, adam, true);
+            vals[k] = w; mvals[k] = m; vvals[k] = v;
+        } else {
+            gvals[k] = g;
+        }
+    }
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nrows; r += stride) {
+        float g = 0.f;
+        for (int cb = 0; cb < ncb; ++cb) g += bpart[(int64_t)cb * nrows + r];
+        const int node = r < n_term_rows ? first_term_node + (int)r : C + ((int)r - n_term_rows);
+        if (apply_update) {
+            float w = bias[node], m = mbias[node], v = vbias[node];
+            ov_adamw(w, m, v, g, adam, false);
+            bias[node] = w; mbias[node] = m; vbias[node] = v;
+        } else {
+            gbias[node] = g;
+        }
+    }
+}
+
 // Weight gradient at mask positions only (SDDMM) + fused AdamW + clamp(0), one wave per row node:
 //   g_k = sum_b D[n, b] * ACT[colidx[k], b];   gb = sum_b D[n, b]
 // The padded batch columns of D are zero by construction, so no masking is needed in the dots.
@@ -1585,7 +1682,7 @@ struct OvSide {
 static OvSide g_side[64];
 
 static OvSide* ov_side_get(const ontovae_ctx_t* c) {
-    if (c->flags & ONTOVAE_FLAG_SINGLE_STREAM) return nullptr;
+    if (!(c->flags & ONTOVAE_FLAG_SIDE_STREAM)) return nullptr;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     OvSide& s = g_side[dev];
@@ -2029,12 +2126,29 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         const int nrows = n_term_rows + d.G;
         float* G_ = c->Gr;
         OvProfScope prof(ONTOVAE_PHASE_DEC_WGRAD, sst);
-        hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((nrows + 3) / 4), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act, s.ws.d,
-                           c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
-                           G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
-                           c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, nrows, 0, n_term_rows, d.C, s.ldb,
-                           apply, adam);
-        OV_LAUNCH_CHECK();
+        if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
+            const int ncb = s.ldb / 32, ntiles = (nrows + 31) / 32;
+            float* part = s.ws.wpart;
+            float* bpart = part + (int64_t)ncb * d.nnz;
+            // the kernel's rows: nodes [0, C - L) then the genes; their entries are the packed range [0, nnz)
+            hipLaunchKernelGGL(ov_wgrad_cb_kernel, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act,
+                               s.ws.d, part, bpart, (int64_t)d.nnz, nrows, 0, n_term_rows, d.C, s.ldb, ncb, ntiles);
+            OV_LAUNCH_CHECK();
+            const int blocks = (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 2048);
+            hipLaunchKernelGGL(ov_wgrad_finish_kernel, dim3(blocks), dim3(256), 0, sst, part, bpart, ncb, (int64_t)0, (int64_t)d.nnz,
+                               (int64_t)d.nnz, nrows, 0, n_term_rows, d.C, c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr,
+                               c->V ? c->V + lay.dec_vals : nullptr, G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias,
+                               c->M ? c->M + lay.dec_bias : nullptr, c->V ? c->V + lay.dec_bias : nullptr,
+                               G_ ? G_ + lay.dec_bias : nullptr, apply, adam);
+            OV_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((nrows + 3) / 4), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act, s.ws.d,
+                               c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
+                               G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
+                               c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, nrows, 0, n_term_rows, d.C, s.ldb,
+                               apply, adam);
+            OV_LAUNCH_CHECK();
+        }
     }
     // latent backward
     {
@@ -2056,8 +2170,10 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         if ((rc = ov_launch_gemm<1, 1, 4, 4, false, false, OV_EPI_STORE>(g, 1, false, s.st))) return rc;
     }
     // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv): side stream, after da has read Wh
-    if ((rc = ov_side_sync_mid(s))) return rc;
+    const bool dwh_main = (c->flags & 64u) != 0;
+    if (!dwh_main && (rc = ov_side_sync_mid(s))) return rc;
     {
+        const hipStream_t sst = dwh_main ? s.st : ov_side_stream(s);
         OvGemm g{};
         g.M = 2 * d.L; g.N = d.L; g.K = s.B;
         g.A = s.ws.dmulv; g.lda = s.ldb;
@@ -2137,7 +2253,7 @@ extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, cons
     ov_make_step(ctx, x, xidx, B, stream, &s);
     s.side = ov_side_get(ctx);
     bool refreshed = false;
-    if (s.side && ov_fused_bt(ctx) != 0) {      // packed decoder weight copies || encoder
+    if (s.side && ov_fused_bt(ctx) != 0 && (ctx->flags & 32u)) {      // packed decoder weight copies || encoder (measurement only)
         if ((rc = ov_side_fork(s))) return rc;
         if ((rc = ov_sell_refresh(s, s.side->st))) return rc;
         refreshed = true;
