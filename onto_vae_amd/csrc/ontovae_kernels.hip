@@ -355,14 +355,32 @@ __global__ __launch_bounds__(256) void ov_bn_bwd_kernel(const float* __restrict_
 // mulv[0:L] = mu, mulv[L:2L] = log_var (feature-major, bias already added by the GEMM epilogue).
 // z = mu + eps * exp(0.5 * log_var)     (vae_model.py:91-93)  -> panel rows of level 0
 // kl = -0.5 * sum(1 + lv - mu^2 - exp(lv))   (vae_model.py:124), block partials in kl_part
+// Blocks beyond nrep do an unrelated job that is due at the same point of a pass and would otherwise be a launch of
+// its own: the refresh of the SELL-ordered weight copies of the term layers from the parameter buffer.
+struct OvRefresh {
+    const float* vals; const float* bias;
+    const int32_t* kf; float* wf; int nf;
+    const int32_t* nodef; float* biasf; int nbf;
+    const int32_t* kb; float* wb; int nb;
+};
+__device__ __forceinline__ void ov_sell_refresh_part(const OvRefresh& r, int first, int stride) {
+    for (int i = first; i < r.nf; i += stride) { const int k = r.kf[i]; r.wf[i] = k >= 0 ? r.vals[k] : 0.f; }
+    for (int i = first; i < r.nbf; i += stride) { const int n = r.nodef[i]; r.biasf[i] = n >= 0 ? r.bias[n] : 0.f; }
+    for (int i = first; i < r.nb; i += stride) { const int k = r.kb[i]; r.wb[i] = k >= 0 ? r.vals[k] : 0.f; }
+}
+
 __global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mulv, const float* __restrict__ eps,
                                                         float* __restrict__ epsw, float* __restrict__ zrows,
                                                         float* __restrict__ kl_part, int L, int B, int ldb, int train,
                                                         float z_drop, uint64_t seed, uint64_t rng_off, uint32_t eps_stream,
-                                                        int write_kl) {
+                                                        int write_kl, int nrep, const OvRefresh rf) {
+    if ((int)blockIdx.x >= nrep) {
+        ov_sell_refresh_part(rf, ((int)blockIdx.x - nrep) * 256 + threadIdx.x, ((int)gridDim.x - nrep) * 256);
+        return;
+    }
     const int64_t n = (int64_t)L * ldb;
     float kl = 0.f;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)nrep * 256) {
         const int l = (int)(idx / ldb), b = (int)(idx % ldb);
         float z = 0.f, e = 0.f;
         if (b < B) {
@@ -392,14 +410,43 @@ __global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mul
     }
 }
 
-// dmu = dz + kc*mu ; dlv = dz * eps * 0.5 * sigma + 0.5*kc*(exp(lv) - 1), then back through z_drop
+// dmu = dz + kc*mu ; dlv = dz * eps * 0.5 * sigma + 0.5*kc*(exp(lv) - 1), then back through z_drop.
+// One wave per latent feature l (rows l and L + l of dmulv).  Two small jobs that are due at the same point ride
+// along instead of being launches of their own: the row sums of dmulv are the gradient of the head biases
+// (AdamW applied here, or stored when apply_update == 0), and the LAST block does the final reduction of the loss
+// partials (loss = rec + kl_coeff * kl, vae_model.py:129).
+struct OvLossArgs { const float* rec_part; int nrec; const float* kl_part; int nkl; float kc; float* out; };
 __global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mulv,
                                                            const float* __restrict__ epsw, float* __restrict__ dmulv,
                                                            int L, int B, int ldb, float kc, float z_drop, uint64_t seed,
-                                                           uint64_t rng_off) {
+                                                           uint64_t rng_off, float* __restrict__ bh, float* __restrict__ mbh,
+                                                           float* __restrict__ vbh, float* __restrict__ gbh, int apply_update,
+                                                           OvAdam adam, const OvLossArgs la) {
+    const int lane = ov_lane();
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ double red[2][4];
+        double r = 0.0, k = 0.0;
+        for (int i = threadIdx.x; i < la.nrec; i += 256) r += (double)la.rec_part[i];
+        for (int i = threadIdx.x; i < la.nkl; i += 256) k += (double)la.kl_part[i];
+        r = ov_wave_sum_d(r);
+        k = ov_wave_sum_d(k);
+        if (lane == 0) { red[0][threadIdx.x >> 6] = r; red[1][threadIdx.x >> 6] = k; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float rf = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            const float kf = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+            la.out[0] = rf;
+            la.out[1] = kf;
+            la.out[2] = rf + la.kc * kf;
+        }
+        return;
+    }
+    const int l = blockIdx.x * 4 + ov_wave_id();
+    if (l >= L) return;
     const int64_t n = (int64_t)L * ldb;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
-        const int l = (int)(idx / ldb), b = (int)(idx % ldb);
+    float smu = 0.f, slv = 0.f;
+    for (int b = lane; b < ldb; b += 64) {
+        const int64_t idx = (int64_t)l * ldb + b;
         float dmu = 0.f, dlv = 0.f;
         if (b < B) {
             const float mu = mulv[idx], lv = mulv[n + idx], g = dz[idx], e = epsw[idx];
@@ -412,6 +459,21 @@ __global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const float* __restr
         }
         dmulv[idx] = dmu;
         dmulv[n + idx] = dlv;
+        smu += dmu;
+        slv += dlv;
+    }
+    smu = ov_wave_sum(smu);
+    slv = ov_wave_sum(slv);
+    if (lane < 2) {                     // lane 0: bias of mu[l]; lane 1: bias of log_var[l]
+        const int r = lane == 0 ? l : L + l;
+        const float g = lane == 0 ? smu : slv;
+        if (apply_update) {
+            float ww = bh[r], mm = mbh[r], vv = vbh[r];
+            ov_adamw(ww, mm, vv, g, adam, false);
+            bh[r] = ww; mbh[r] = mm; vbh[r] = vv;
+        } else {
+            gbh[r] = g;
+        }
     }
 }
 
@@ -597,14 +659,8 @@ __device__ __forceinline__ void ov_group_sum_rt(float (&acc)[BT], int lg) {
 }
 
 // Refresh of the SELL-ordered weight copies from the parameter buffer (start of every pass).
-__global__ __launch_bounds__(256) void ov_sell_refresh_kernel(const float* __restrict__ vals, const float* __restrict__ bias,
-                                                             const int32_t* __restrict__ kf, float* __restrict__ wf, int nf,
-                                                             const int32_t* __restrict__ nodef, float* __restrict__ biasf, int nbf,
-                                                             const int32_t* __restrict__ kb, float* __restrict__ wb, int nb) {
-    const int stride = gridDim.x * 256;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf; i += stride) { const int k = kf[i]; wf[i] = k >= 0 ? vals[k] : 0.f; }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nbf; i += stride) { const int n = nodef[i]; biasf[i] = n >= 0 ? bias[n] : 0.f; }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) { const int k = kb[i]; wb[i] = k >= 0 ? vals[k] : 0.f; }
+__global__ __launch_bounds__(256) void ov_sell_refresh_kernel(const OvRefresh rf) {
+    ov_sell_refresh_part(rf, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1770,15 +1826,33 @@ static int ov_heads_fwd(OvStep& s) {
     return ov_launch_gemm<1, 1, 4, 4, true, false, OV_EPI_BIAS>(g, 1, vec, s.st);
 }
 
-static int ov_reparam(OvStep& s, const float* eps, int train, uint64_t rng_off, uint32_t eps_stream, int write_kl, int* nkl) {
+static int ov_fused_bt(const ontovae_ctx_t* c);
+// arguments of the SELL weight refresh; blocks = 0 if this model does not use the fused chain
+static int ov_refresh_args(const ontovae_ctx_t* c, OvRefresh* r) {
+    *r = OvRefresh{};
+    if (ov_fused_bt(c) == 0) return 0;
+    const ontovae_sell_t& f = c->sell_fwd;
+    const ontovae_sell_t& b = c->sell_bwd;
+    r->vals = c->P + c->lay.dec_vals; r->bias = c->P + c->lay.dec_bias;
+    r->kf = f.k; r->wf = f.w; r->nf = f.n_chunks * 512;
+    r->nodef = f.node; r->biasf = f.bias; r->nbf = f.n_slices * 64;
+    r->kb = b.k; r->wb = b.w; r->nb = b.n_chunks * 512;
+    return std::min(512, (std::max(r->nf, r->nb) + 255) / 256);
+}
+
+// with_refresh: the launch also refreshes the packed term-layer weights (callers then skip ov_sell_refresh)
+static int ov_reparam(OvStep& s, const float* eps, int train, uint64_t rng_off, uint32_t eps_stream, int write_kl, int* nkl,
+                      bool with_refresh) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     const int64_t n = (int64_t)d.L * s.ldb;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
     float* zrows = s.ws.act + (int64_t)(d.C - d.L) * s.ldb;
+    OvRefresh rf{};
+    const int rblocks = with_refresh ? ov_refresh_args(c, &rf) : 0;
     OvProfScope prof(ONTOVAE_PHASE_REPARAM, s.st);
-    hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks), dim3(256), 0, s.st, s.ws.mulv, eps, s.ws.epsw, zrows, s.ws.kl_part, d.L,
-                       s.B, s.ldb, train, c->z_drop, c->seed, rng_off, eps_stream, write_kl);
+    hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks + rblocks), dim3(256), 0, s.st, s.ws.mulv, eps, s.ws.epsw, zrows, s.ws.kl_part,
+                       d.L, s.B, s.ldb, train, c->z_drop, c->seed, rng_off, eps_stream, write_kl, blocks, rf);
     OV_LAUNCH_CHECK();
     if (nkl) *nkl = blocks;
     return ONTOVAE_OK;
@@ -1829,15 +1903,11 @@ static int ov_set_lds(KernelT kernel, size_t bytes) {
 
 // SELL weight copies <- parameter buffer; called once per pass before the first chain kernel
 static int ov_sell_refresh(OvStep& s, hipStream_t st) {
-    const ontovae_ctx_t* c = s.c;
-    if (ov_fused_bt(c) == 0) return ONTOVAE_OK;
-    const ontovae_sell_t& f = c->sell_fwd;
-    const ontovae_sell_t& b = c->sell_bwd;
-    const int nf = f.n_chunks * 512, nbf = f.n_slices * 64, nb = b.n_chunks * 512;
-    const int blocks = std::min(512, (std::max(nf, nb) + 255) / 256);
+    OvRefresh rf{};
+    const int blocks = ov_refresh_args(s.c, &rf);
+    if (blocks == 0) return ONTOVAE_OK;
     OvProfScope prof(ONTOVAE_PHASE_SELL_REFRESH, st);
-    hipLaunchKernelGGL(ov_sell_refresh_kernel, dim3(blocks), dim3(256), 0, st, c->P + c->lay.dec_vals, c->P + c->lay.dec_bias,
-                       f.k, f.w, nf, f.node, f.bias, nbf, b.k, b.w, nb);
+    hipLaunchKernelGGL(ov_sell_refresh_kernel, dim3(blocks), dim3(256), 0, st, rf);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
@@ -1995,7 +2065,7 @@ static int ov_encode(OvStep& s, const float* eps, int train, uint64_t rng_off, u
     if ((rc = ov_enc_gemm(s, &S))) return rc;
     if ((rc = ov_bn_fwd(s, S, train ? 1 : 0, s.B, nullptr, rng_off))) return rc;
     if ((rc = ov_heads_fwd(s))) return rc;
-    return ov_reparam(s, eps, train, rng_off, eps_stream, write_kl, nkl);
+    return ov_reparam(s, eps, train, rng_off, eps_stream, write_kl, nkl, true);     // also refreshes the packed term-layer weights
 }
 
 static int ov_transpose_out(OvStep& s, const float* src, int F, float* dst, int64_t ld) {
@@ -2021,7 +2091,7 @@ extern "C" int ontovae_forward(const ontovae_ctx_t* ctx, const float* x, const i
     if (mu && (rc = ov_transpose_out(s, s.ws.mulv, d.L, mu, d.L))) return rc;
     if (log_var && (rc = ov_transpose_out(s, s.ws.mulv + (int64_t)d.L * s.ldb, d.L, log_var, d.L))) return rc;
     if (recon) {
-        if ((rc = ov_dec_forward_terms(s))) return rc;
+        if ((rc = ov_dec_forward_terms(s, true))) return rc;
         if ((rc = ov_dec_gene<2>(s, recon, d.G))) return rc;
     }
     return ONTOVAE_OK;
@@ -2036,7 +2106,7 @@ extern "C" int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const
     ov_make_step(ctx, x, xidx, B, stream, &s);
     int nkl = 0;
     if ((rc = ov_encode(s, eps, 0, rng_offset, OV_RNG_EPS, 1, &nkl))) return rc;
-    if ((rc = ov_dec_forward_terms(s))) return rc;
+    if ((rc = ov_dec_forward_terms(s, true))) return rc;
     if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
     return ov_loss_finalize(s, s.st, ov_nrec(s), nkl, kl_coeff, loss_out);
 }
@@ -2071,8 +2141,8 @@ extern "C" int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const
     // the same mu / log_var, so one encoder pass and two reparameterisations are identical.
     if ((rc = ov_encode(s, eps1, 0, rng_offset, OV_RNG_EPS, 0, nullptr))) return rc;
     if (act_out && (rc = ov_act_out(s, 0, 1, act_out, act_ld))) return rc;          // z part from draw #1
-    if ((rc = ov_reparam(s, eps2, 0, rng_offset, OV_RNG_EPS2, 0, nullptr))) return rc;  // draw #2 feeds the decoder
-    if ((rc = ov_dec_forward_terms(s))) return rc;
+    if ((rc = ov_reparam(s, eps2, 0, rng_offset, OV_RNG_EPS2, 0, nullptr, false))) return rc;  // draw #2 feeds the decoder
+    if ((rc = ov_dec_forward_terms(s, true))) return rc;
     if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld))) return rc;
     if (rec_out && (rc = ov_dec_gene<2>(s, rec_out, rec_ld))) return rc;
     return ONTOVAE_OK;
@@ -2111,15 +2181,14 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     const OvAdam adam = ov_adam_from(opt);
     int rc, nkl = 0;
     if ((rc = ov_heads_fwd(s))) return rc;
-    if ((rc = ov_reparam(s, eps, 1, rng_off, OV_RNG_EPS, 1, &nkl))) return rc;
+    if ((rc = ov_reparam(s, eps, 1, rng_off, OV_RNG_EPS, 1, &nkl, !refreshed))) return rc;
     if (refreshed && (rc = ov_side_join(s))) return rc;          // packed decoder weights ready
-    if ((rc = ov_dec_forward_terms(s, refreshed))) return rc;
+    if ((rc = ov_dec_forward_terms(s, true))) return rc;
     if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
     if ((rc = ov_dec_backward(s))) return rc;
-    // fork: the decoder's weight gradients and the loss need nothing from the encoder backward, and vice versa
+    // fork: the decoder's weight gradients need nothing from the encoder backward, and vice versa
     if ((rc = ov_side_fork(s))) return rc;
     const hipStream_t sst = ov_side_stream(s);
-    if ((rc = ov_loss_finalize(s, sst, ov_nrec(s), nkl, kc, loss_out))) return rc;
     // decoder weight gradients (+ AdamW + clamp)
     {
         const int n_term_rows = d.C - d.L;
@@ -2150,13 +2219,14 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
             OV_LAUNCH_CHECK();
         }
     }
-    // latent backward
+    // latent backward (+ head bias gradient / AdamW, + final reduction of the loss partials)
     {
-        const int64_t n = (int64_t)d.L * s.ldb;
-        const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
+        OvLossArgs la{s.ws.rec_part, ov_nrec(s), s.ws.kl_part, nkl, kc, loss_out};
         OvProfScope prof(ONTOVAE_PHASE_LATENT_BWD, s.st);
-        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(blocks), dim3(256), 0, s.st, s.ws.d + (int64_t)(d.C - d.L) * s.ldb, s.ws.mulv,
-                           s.ws.epsw, s.ws.dmulv, d.L, s.B, s.ldb, kc, c->z_drop, c->seed, rng_off);
+        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3((d.L + 3) / 4 + 1), dim3(256), 0, s.st, s.ws.d + (int64_t)(d.C - d.L) * s.ldb,
+                           s.ws.mulv, s.ws.epsw, s.ws.dmulv, d.L, s.B, s.ldb, kc, c->z_drop, c->seed, rng_off, c->P + lay.bh,
+                           c->M ? c->M + lay.bh : nullptr, c->V ? c->V + lay.bh : nullptr, c->Gr ? c->Gr + lay.bh : nullptr, apply,
+                           adam, la);
         OV_LAUNCH_CHECK();
     }
     // da = Wh^T dmulv  (before Wh is updated)
@@ -2188,10 +2258,6 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
             g.C = c->Gr + lay.Wh;
             if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_STORE>(g, 1, true, sst))) return rc;
         }
-        hipLaunchKernelGGL(ov_rowsum_adamw_kernel, dim3((2 * d.L + 3) / 4), dim3(256), 0, sst, s.ws.dmulv, 2 * d.L, s.ldb,
-                           c->P + lay.bh, c->M ? c->M + lay.bh : nullptr, c->V ? c->V + lay.bh : nullptr,
-                           c->Gr ? c->Gr + lay.bh : nullptr, apply, adam);
-        OV_LAUNCH_CHECK();
     }
     // BN backward
     {

@@ -5,7 +5,7 @@ from onto_vae_amd.vae_model import FusedAdamW
 dev = torch.device('cuda',0)
 model, masks = bench.build_model(dev)
 e = model._engine
-e.flags = 4; e.invalidate()
+e.flags = 0; e.invalidate()
 X = bench.synth_X(4096, 20000, dev)
 opt = FusedAdamW(model, lr=1e-4)
 loss = torch.zeros(3, device=dev)
