@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void ov_bn_bwd_kernel(const float* __restrict_
                                                        float* __restrict__ dh, float* __restrict__ bwd_local,
                                                        float* __restrict__ bwd_stats, int L, int B, int Bglobal, int ldb,
                                                        int mode, int apply_update, OvAdam adam, float drop, uint64_t seed,
-                                                       uint64_t rng_off) {
+                                                       uint64_t rng_off, int daS, int64_t dastride) {
     const int l = blockIdx.x * 4 + ov_wave_id();
     if (l >= L) return;
     const int lane = ov_lane();
@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256) void ov_bn_bwd_kernel(const float* __restrict_
         for (int b = lane; b < ldb; b += 64) {
             float dy = 0.f;
             if (b < B) {
-                dy = a[ro + b] > 0.f ? da[ro + b] : 0.f;
+                if (a[ro + b] > 0.f)
+                    for (int q = 0; q < daS; ++q) dy += da[q * dastride + ro + b];      // split-K partials of the da GEMM
                 if (drop > 0.f) dy *= ov_dropout_scale(drop, seed, rng_off, OV_RNG_DROP, (uint64_t)l * 0x100000000ull + b);
                 sdy += dy;
                 sdyx += dy * xhat[ro + b];
@@ -373,7 +374,9 @@ __global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mul
                                                         float* __restrict__ epsw, float* __restrict__ zrows,
                                                         float* __restrict__ kl_part, int L, int B, int ldb, int train,
                                                         float z_drop, uint64_t seed, uint64_t rng_off, uint32_t eps_stream,
-                                                        int write_kl, int nrep, const OvRefresh rf) {
+                                                        int write_kl, int nrep, const OvRefresh rf,
+                                                        const float* __restrict__ hslab, int hS, int64_t hstride,
+                                                        const float* __restrict__ bh) {
     if ((int)blockIdx.x >= nrep) {
         ov_sell_refresh_part(rf, ((int)blockIdx.x - nrep) * 256 + threadIdx.x, ((int)gridDim.x - nrep) * 256);
         return;
@@ -384,10 +387,20 @@ __global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mul
         const int l = (int)(idx / ldb), b = (int)(idx % ldb);
         float z = 0.f, e = 0.f;
         if (b < B) {
-            float mu = mulv[idx], lv = mulv[n + idx];
+            float mu, lv;
+            if (hslab) {          // heads GEMM left split-K partials: mu / log_var = bias + sum of the slabs (modules.py:57, 62)
+                mu = bh[l];
+                lv = bh[L + l];
+                for (int q = 0; q < hS; ++q) { mu += hslab[q * hstride + idx]; lv += hslab[q * hstride + n + idx]; }
+            } else {
+                mu = mulv[idx];
+                lv = mulv[n + idx];
+            }
             if (train && z_drop > 0.f) {
                 mu *= ov_dropout_scale(z_drop, seed, rng_off, OV_RNG_ZDROP_MU, (uint64_t)l * 0x100000000ull + b);
                 lv *= ov_dropout_scale(z_drop, seed, rng_off, OV_RNG_ZDROP_LV, (uint64_t)l * 0x100000000ull + b);
+            }
+            if (hslab || (train && z_drop > 0.f)) {
                 mulv[idx] = mu;
                 mulv[n + idx] = lv;
             }
@@ -1722,6 +1735,7 @@ struct OvStep {
     const float* x;
     const int32_t* xidx;
     int64_t xld;
+    int heads_S;             // split-K slabs the heads GEMM left in ws.slab (0: mu / log_var are already in ws.mulv)
     struct OvSide* side;     // internal second stream of this device, or NULL (ONTOVAE_FLAG_SINGLE_STREAM / creation failed)
 };
 
@@ -1819,11 +1833,15 @@ static int ov_heads_fwd(OvStep& s) {
     g.M = 2 * d.L; g.N = s.B; g.K = d.L;
     g.A = c->P + c->lay.Wh; g.lda = d.L;
     g.B = s.ws.a; g.ldb = s.ldb; g.bgather = nullptr;
-    g.C = s.ws.mulv; g.ldc = s.ldb; g.kchunk = (d.L + 31) / 32 * 32;
-    g.bias = c->P + c->lay.bh;
+    // split-K partials into the (now free) encoder slab buffer; ov_reparam adds them and the bias
+    const int64_t one = (int64_t)2 * d.L * s.ldb;
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(3, s.ws.slab_floats / one));
+    int kchunk = ((d.L + S - 1) / S + 31) / 32 * 32;
+    g.C = s.ws.slab; g.ldc = s.ldb; g.slab_stride = one; g.kchunk = kchunk;
+    s.heads_S = (d.L + kchunk - 1) / kchunk;
     const bool vec = (d.L % 4 == 0) && ov_al16(g.A);
     OvProfScope prof(ONTOVAE_PHASE_HEADS, s.st);
-    return ov_launch_gemm<1, 1, 4, 4, true, false, OV_EPI_BIAS>(g, 1, vec, s.st);
+    return ov_launch_gemm<1, 1, 4, 4, true, false, OV_EPI_STORE>(g, s.heads_S, vec, s.st);
 }
 
 static int ov_fused_bt(const ontovae_ctx_t* c);
@@ -1852,8 +1870,10 @@ static int ov_reparam(OvStep& s, const float* eps, int train, uint64_t rng_off, 
     const int rblocks = with_refresh ? ov_refresh_args(c, &rf) : 0;
     OvProfScope prof(ONTOVAE_PHASE_REPARAM, s.st);
     hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks + rblocks), dim3(256), 0, s.st, s.ws.mulv, eps, s.ws.epsw, zrows, s.ws.kl_part,
-                       d.L, s.B, s.ldb, train, c->z_drop, c->seed, rng_off, eps_stream, write_kl, blocks, rf);
+                       d.L, s.B, s.ldb, train, c->z_drop, c->seed, rng_off, eps_stream, write_kl, blocks, rf,
+                       s.heads_S > 0 ? s.ws.slab : (const float*)nullptr, s.heads_S, (int64_t)2 * d.L * s.ldb, c->P + c->lay.bh);
     OV_LAUNCH_CHECK();
+    s.heads_S = 0;               // mu / log_var are in ws.mulv from here on
     if (nkl) *nkl = blocks;
     return ONTOVAE_OK;
 }
@@ -2055,6 +2075,7 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->x = x;
     s->xidx = xidx;
     s->xld = ctx->dims.G;
+    s->heads_S = 0;
     s->side = nullptr;
     return ONTOVAE_OK;
 }
@@ -2230,14 +2251,20 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         OV_LAUNCH_CHECK();
     }
     // da = Wh^T dmulv  (before Wh is updated)
+    int da_S = 1;
     {
         OvGemm g{};
         g.M = d.L; g.N = s.B; g.K = 2 * d.L;
         g.A = c->P + lay.Wh; g.lda = d.L;          // A(m=l, k=j) = Wh[j*L + l]
         g.B = s.ws.dmulv; g.ldb = s.ldb;
-        g.C = s.ws.da; g.ldc = s.ldb; g.kchunk = (2 * d.L + 31) / 32 * 32;
+        // split-K partials into the (free) encoder slab buffer; the BatchNorm backward adds them
+        const int64_t one = (int64_t)d.L * s.ldb;
+        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(4, s.ws.slab_floats / one));
+        const int kchunk = ((2 * d.L + S - 1) / S + 31) / 32 * 32;
+        da_S = (2 * d.L + kchunk - 1) / kchunk;
+        g.C = da_S > 1 ? s.ws.slab : s.ws.da; g.ldc = s.ldb; g.slab_stride = one; g.kchunk = kchunk;
         OvProfScope prof(ONTOVAE_PHASE_DA_GEMM, s.st);
-        if ((rc = ov_launch_gemm<1, 1, 4, 4, false, false, OV_EPI_STORE>(g, 1, false, s.st))) return rc;
+        if ((rc = ov_launch_gemm<1, 1, 4, 4, false, false, OV_EPI_STORE>(g, da_S, false, s.st))) return rc;
     }
     // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv): side stream, after da has read Wh
     const bool dwh_main = (c->flags & 64u) != 0;
@@ -2263,12 +2290,12 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     {
         float* Gr = c->Gr;
         OvProfScope prof(ONTOVAE_PHASE_BN_BWD, s.st);
-        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd,
-                           c->P + lay.gamma, c->P + lay.beta, c->P + lay.b0, c->M ? c->M + lay.gamma : nullptr,
+        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, da_S > 1 ? s.ws.slab : s.ws.da, s.ws.a, s.ws.xhat,
+                           s.ws.bn_invstd, c->P + lay.gamma, c->P + lay.beta, c->P + lay.b0, c->M ? c->M + lay.gamma : nullptr,
                            c->M ? c->M + lay.beta : nullptr, c->M ? c->M + lay.b0 : nullptr, c->V ? c->V + lay.gamma : nullptr,
                            c->V ? c->V + lay.beta : nullptr, c->V ? c->V + lay.b0 : nullptr, Gr ? Gr + lay.gamma : nullptr,
                            Gr ? Gr + lay.beta : nullptr, Gr ? Gr + lay.b0 : nullptr, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L,
-                           s.B, Bglobal, s.ldb, bn_mode, apply, adam, c->drop, c->seed, rng_off);
+                           s.B, Bglobal, s.ldb, bn_mode, apply, adam, c->drop, c->seed, rng_off, da_S, (int64_t)d.L * s.ldb);
         OV_LAUNCH_CHECK();
     }
     return ONTOVAE_OK;
@@ -2357,7 +2384,7 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
         hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd,
                            ctx->P + lay.gamma, ctx->P + lay.beta, ctx->P + lay.b0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            ctx->Gr + lay.gamma, ctx->Gr + lay.beta, ctx->Gr + lay.b0, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, B,
-                           B_global, s.ldb, 3, 0, adam, ctx->drop, ctx->seed, rng_offset);
+                           B_global, s.ldb, 3, 0, adam, ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0);
         OV_LAUNCH_CHECK();
         return ov_dw0(s, nullptr, 0);
     }
