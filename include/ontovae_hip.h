@@ -109,7 +109,9 @@ int ontovae_plan_unpack_mask(const ontovae_plan_t* plan, int32_t layer, uint8_t*
  * of 64 lanes; a node of up to 8 entries owns one lane, longer nodes own 2, 4, .. 64 adjacent lanes
  * (their partial sums are combined with DPP), and a lane holds its entries in 64x8 chunks
  * ([8][64] index / weight-position arrays, so every load of a slice is one contiguous 256-B row per
- * entry slot).  info[lane] = entries of the lane | log2(lanes per node) << 16 | writer lane << 24.
+ * entry slot).  info[lane] = entries of the lane | log2(lanes per node) << 16 | entries per lane of the
+ * slice (its width, <= 8) << 20 | writer lane << 24.  Padding slots have k = -1 (weight 0) and the index
+ * of a row the slice really reads.
  * The library keeps a weight copy in this order (`w`, refreshed from P at the start of every pass). */
 typedef struct ontovae_sell {
     int32_t n_levels;
