@@ -724,14 +724,25 @@ __device__ __forceinline__ void ov_rec_load(OvRec& r, int sl, int lane, const in
     r.bias = BWD ? 0.f : sbias[sl * 64 + lane];
 }
 
+struct OvChainArgs {
+    const int32_t* snode; const int32_t* sinfo; const int32_t* chunk0; const int32_t* sidx;
+    const float* sw; const float* sbias;
+    float* glob; const float* inblk;
+    int ldb, in0, in1, out0, out1, dbg;
+};
 template <int BT, bool BWD, bool SINGLE>
-__global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __restrict__ snode, const int32_t* __restrict__ sinfo,
-                                                          const int32_t* __restrict__ chunk0, const int32_t* __restrict__ sidx,
-                                                          const float* __restrict__ sw, const float* __restrict__ sbias,
-                                                          float* __restrict__ glob, const float* __restrict__ inblk, int ldb,
-                                                          int in0, int in1, int out0, int out1, const OvSteps st, int dbg) {
+__device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const OvSteps& st, const int block) {
+    const int32_t* __restrict__ snode = ca.snode;
+    const int32_t* __restrict__ sinfo = ca.sinfo;
+    const int32_t* __restrict__ chunk0 = ca.chunk0;
+    const int32_t* __restrict__ sidx = ca.sidx;
+    const float* __restrict__ sw = ca.sw;
+    const float* __restrict__ sbias = ca.sbias;
+    float* __restrict__ glob = ca.glob;
+    const float* __restrict__ inblk = ca.inblk;
+    const int ldb = ca.ldb, in0 = ca.in0, in1 = ca.in1, out0 = ca.out0, out1 = ca.out1, dbg = ca.dbg;
     extern __shared__ __attribute__((aligned(16))) float ov_panel[];
-    const int b0 = blockIdx.x * BT;
+    const int b0 = block * BT;
     const int lane = ov_lane();
     const int wave = ov_wave_id();
     OV_CPROBE(0);
@@ -752,7 +763,7 @@ __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __res
     // prologue: the rows the chain starts from, HBM -> LDS.  FWD: level 0 (z).  BWD: every panel row
     // (the gene layer's contribution, written by the gene backward kernel).
     // inblk (BT == 4 only): the same rows in column-group-major order, one contiguous piece per workgroup
-    const float* src = (BT == 4 && inblk) ? inblk + (int64_t)blockIdx.x * out1 * 4 : glob + b0;
+    const float* src = (BT == 4 && inblk) ? inblk + (int64_t)block * out1 * 4 : glob + b0;
     const int64_t src_ld = (BT == 4 && inblk) ? 4 : ldb;
     for (int p = in0 + threadIdx.x; p < in1; p += 8 * 1024) {
         float v[8][BT];
@@ -848,6 +859,11 @@ __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const int32_t* __res
         ov_stv<BT>(glob + (int64_t)p * ldb + b0, v);
     }
     OV_CPROBE(31);
+}
+
+template <int BT, bool BWD, bool SINGLE>
+__global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const OvChainArgs ca, const OvSteps st) {
+    ov_dec_chain_body<BT, BWD, SINGLE>(ca, st, blockIdx.x);
 }
 
 // Cooperative entry prefetch for the row-per-wave gather kernels: the 64 lanes load up to 64
@@ -1141,10 +1157,11 @@ __device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const
 }
 
 // The 32 rows of a tile are dealt to the lane groups in order of decreasing list length (rank by counting in
-// LDS), so that the 8 groups of a wave walk lists of similar length.  Call with all 256 threads; returns the
+// LDS), so that the 8 groups of a wave walk lists of similar length.  Call with all threads of the workgroup (tid is
+// the thread's number inside its 256-thread tile team; every team has its own three arrays); returns the
 // tile-local row of this thread's group and its list (k0, len).
-__device__ __forceinline__ int ov_tile_balance(int my_k0, int my_len, int* sh_k0, int* sh_len, int* sh_ord, int& k0, int& len) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ int ov_tile_balance(int my_k0, int my_len, int* sh_k0, int* sh_len, int* sh_ord, int& k0, int& len,
+                                               int tid = threadIdx.x) {
     if (tid < 32) { sh_k0[tid] = my_k0; sh_len[tid] = my_len; }
     __syncthreads();
     if (tid < 32) {
@@ -1315,44 +1332,51 @@ __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restri
 // line per group), and a dot needs 3 DPP adds within the group instead of a wave-wide reduction.  The column
 // blocks are pinned to XCDs like the other gene-layer kernels, so the panel columns a workgroup gathers stay in its
 // L2.  ov_wgrad_finish_kernel adds the blocks' partials in a fixed order and applies AdamW + clamp.
-__global__ __launch_bounds__(256) void ov_wgrad_cb_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                                         const float* __restrict__ act, const float* __restrict__ d,
-                                                         float* __restrict__ part, float* __restrict__ bpart, int64_t nnz, int nrows,
-                                                         int first_term_node, int n_term_rows, int C, int ldb, int ncb, int ntiles) {
-    __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
-    const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
-    if (map.tile >= ntiles) return;
+struct OvWgradArgs {
+    const int32_t* rowptr; const int32_t* colidx; const float* act; const float* d;
+    float* part; float* bpart;
+    int64_t nnz;
+    int row0, nrows_part, nrows;      // this launch covers rows [row0, row0 + nrows_part) of the nrows rows
+    int first_term_node, n_term_rows, C, ldb, ncb, ntiles;
+};
+// wg: virtual workgroup number of the 256-thread team, tid: thread number inside the team.  Every thread of the
+// real workgroup must call this (one workgroup barrier pair inside).
+__device__ __forceinline__ void ov_wgrad_cb_body(const OvWgradArgs& a, int wg, int tid, int* sh_k0, int* sh_len, int* sh_ord) {
+    const OvCbMap map = ov_cb_map(wg, a.ncb);
+    const bool tile_on = map.tile < a.ntiles;
     const int lane = ov_lane();
     const int s = lane & 7;
     const int col0 = map.cb * 32, s4 = 4 * s;
-    auto node_of = [&](int r) { return r < n_term_rows ? first_term_node + r : C + (r - n_term_rows); };
+    auto node_of = [&](int r) { return r < a.n_term_rows ? a.first_term_node + r : a.C + (r - a.n_term_rows); };
+    const int rend = a.row0 + a.nrows_part;
     int my_k0 = 0, my_len = 0;
-    if (threadIdx.x < 32) {
-        const int r = map.tile * 32 + threadIdx.x;
-        if (r < nrows) { const int n = node_of(r); my_k0 = rowptr[n]; my_len = rowptr[n + 1] - my_k0; }
+    if (tile_on && tid < 32) {
+        const int r = a.row0 + map.tile * 32 + tid;
+        if (r < rend) { const int n = node_of(r); my_k0 = a.rowptr[n]; my_len = a.rowptr[n + 1] - my_k0; }
     }
     int k0, len;
-    const int r = map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
-    const bool row_on = r < nrows;
-    const int node = node_of(min(r, nrows - 1));
-    const f32x4 dseg = *reinterpret_cast<const f32x4*>(d + (int64_t)node * ldb + col0 + s4);
+    const int r = a.row0 + map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len, tid);
+    if (!tile_on) return;                            // no barrier below
+    const bool row_on = r < rend;
+    const int node = node_of(min(r, rend - 1));
+    const f32x4 dseg = *reinterpret_cast<const f32x4*>(a.d + (int64_t)node * a.ldb + col0 + s4);
     {
         float gb = (dseg.x + dseg.y) + (dseg.z + dseg.w);
         gb = ov_group_sum<3>(gb);
-        if (row_on && s == 7) bpart[(int64_t)map.cb * nrows + r] = gb;
+        if (row_on && s == 7) a.bpart[(int64_t)map.cb * a.nrows + r] = gb;
     }
     int maxlen = len;                                // wave maximum
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
     maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-    const float* actcol = act + col0 + s4;
-    float* prow = part + (int64_t)map.cb * nnz + k0;
-    auto fetch = [&](int e) { return len > 0 ? colidx[k0 + max(min(e, len - 1), 0)] : 0; };
+    const float* actcol = a.act + col0 + s4;
+    float* prow = a.part + (int64_t)map.cb * a.nnz + k0;
+    auto fetch = [&](int e) { return len > 0 ? a.colidx[k0 + max(min(e, len - 1), 0)] : 0; };
     int cur_c = fetch(s), nxt_c = 0;
     for (int b0 = 0; b0 < maxlen; b0 += 8) {
         if (b0 + 8 < maxlen) nxt_c = fetch(b0 + 8 + s);
         f32x4 v[8];
-#define OV_WG_LOAD(I) v[I] = *reinterpret_cast<const f32x4*>(actcol + (int64_t)ov_grp_bcast<I>(cur_c) * ldb);
+#define OV_WG_LOAD(I) v[I] = *reinterpret_cast<const f32x4*>(actcol + (int64_t)ov_grp_bcast<I>(cur_c) * a.ldb);
         OV_WG_LOAD(0) OV_WG_LOAD(1) OV_WG_LOAD(2) OV_WG_LOAD(3) OV_WG_LOAD(4) OV_WG_LOAD(5) OV_WG_LOAD(6) OV_WG_LOAD(7)
 #undef OV_WG_LOAD
         float mine = 0.f;
@@ -1368,6 +1392,28 @@ __global__ __launch_bounds__(256) void ov_wgrad_cb_kernel(const int32_t* __restr
         if (row_on && b0 + s < len) prow[b0 + s] = mine;
         cur_c = nxt_c;
     }
+}
+
+__global__ __launch_bounds__(256) void ov_wgrad_cb_kernel(const OvWgradArgs a) {
+    __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
+    ov_wgrad_cb_body(a, blockIdx.x, threadIdx.x, sh_k0, sh_len, sh_ord);
+}
+
+// Backward term chain and the gene rows of the weight gradient in ONE launch.  The chain occupies only ldb / BT
+// workgroups (32 CUs at batch 128) for its whole, latency-bound duration, and the gene rows of the weight gradient
+// (everything it needs is final once the gene layer's D rows exist) are the largest piece of independent work of the
+// step: workgroups [0, nchain) run the chain, the others are four 256-thread teams of ov_wgrad_cb_body each.  Low
+// workgroup ids are dispatched first, so the chain starts at once and the rest fills the other CUs.
+template <int BT, bool SINGLE>
+__global__ __launch_bounds__(1024) void ov_chain_bwd_wgrad_kernel(const OvChainArgs ca, const OvSteps st, int nchain,
+                                                                const OvWgradArgs wa) {
+    if ((int)blockIdx.x < nchain) {
+        ov_dec_chain_body<BT, true, SINGLE>(ca, st, blockIdx.x);
+        return;
+    }
+    __shared__ int sh[4][3][32];
+    const int team = threadIdx.x >> 8;
+    ov_wgrad_cb_body(wa, ((int)blockIdx.x - nchain) * 4 + team, threadIdx.x & 255, sh[team][0], sh[team][1], sh[team][2]);
 }
 
 // g_k = sum over column blocks of part[cb][k] (fixed order), then AdamW + clamp(0) (vae_model.py:172-176) or the
@@ -1908,7 +1954,7 @@ static int ov_fused_bt(const ontovae_ctx_t* c) {
         return 0;
     OvSteps tmp;
     if (!ov_make_steps(f, &tmp) || !ov_make_steps(b, &tmp)) return 0;
-    const int64_t lds = 160 * 1024;
+    const int64_t lds = 160 * 1024 - 2048;      // the panel, minus the static LDS of the kernels that carry the chain
     if ((int64_t)d.C * 16 <= lds) return 4;
     if ((int64_t)d.C * 8 <= lds) return 2;
     if ((int64_t)d.C * 4 <= lds) return 1;
@@ -1951,10 +1997,11 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     ov_make_steps(f, &lv);
     const size_t lds = (size_t)d.C * bt * sizeof(float);
     OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
+    const OvChainArgs ca{f.node, f.info, f.chunk0, f.idx, f.w, f.bias, s.ws.act, nullptr, s.ldb, d.C - d.L, d.C, 0, d.C - d.L,
+                         (int)((c->flags >> 8) & 7)};
 #define OV_TF2(BT, SG)                                                                                                \
     if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false, SG>, lds))) return rc;                                         \
-    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, f.node, f.info, f.chunk0, \
-                       f.idx, f.w, f.bias, s.ws.act, (const float*)nullptr, s.ldb, d.C - d.L, d.C, 0, d.C - d.L, lv, (int)(c->flags >> 8))
+    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, ca, lv)
 #define OV_TF(BT) do { if (f.all_single_chunk) { OV_TF2(BT, true); } else { OV_TF2(BT, false); } } while (0)
     if (bt == 4) { OV_TF(4); } else if (bt == 2) { OV_TF(2); } else { OV_TF(1); }
 #undef OV_TF
@@ -2013,7 +2060,11 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne) {
     return ONTOVAE_OK;
 }
 
-static int ov_dec_backward(OvStep& s) {
+#define OV_RIDE_PCT 75      // share of the gene rows whose weight gradient rides in the backward chain's launch (flat from 55 to 100)
+// wg: gene rows of the weight gradient to run in the same launch as the backward chain (fused path only), or NULL;
+// *wg_done tells the caller whether that happened
+static int ov_dec_backward(OvStep& s, const OvWgradArgs* wg = nullptr, bool* wg_done = nullptr) {
+    if (wg_done) *wg_done = false;
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     const int bt = ov_fused_bt(c);
@@ -2045,15 +2096,25 @@ static int ov_dec_backward(OvStep& s) {
     ov_make_steps(sb, &lv);
     const size_t lds = (size_t)d.C * bt * sizeof(float);
     OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
+    const OvChainArgs ca{sb.node, sb.info, sb.chunk0, sb.idx, sb.w, nullptr, s.ws.d, blk, s.ldb, 0, d.C, 0, d.C,
+                         (int)((c->flags >> 8) & 7)};
+    const int nchain = s.ldb / bt;
+    const int wteams = wg ? ov_cb_grid(wg->ncb, wg->ntiles) : 0;
 #define OV_TB2(BT, SG)                                                                                                \
-    if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true, SG>, lds))) return rc;                                          \
-    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, sb.node, sb.info, sb.chunk0, \
-                       sb.idx, sb.w, (const float*)nullptr, s.ws.d, (const float*)blk, s.ldb, 0, d.C, 0, d.C, lv, (int)(c->flags >> 8))
+    if (wg) {                                                                                                         \
+        if ((rc = ov_set_lds(ov_chain_bwd_wgrad_kernel<BT, SG>, lds))) return rc;                                      \
+        hipLaunchKernelGGL((ov_chain_bwd_wgrad_kernel<BT, SG>), dim3(nchain + (wteams + 3) / 4), dim3(1024), lds, s.st, ca, lv,   \
+                           nchain, *wg);                                                                              \
+    } else {                                                                                                          \
+        if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true, SG>, lds))) return rc;                                      \
+        hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true, SG>), dim3(nchain), dim3(1024), lds, s.st, ca, lv);          \
+    }
 #define OV_TB(BT) do { if (sb.all_single_chunk) { OV_TB2(BT, true); } else { OV_TB2(BT, false); } } while (0)
     if (bt == 4) { OV_TB(4); } else if (bt == 2) { OV_TB(2); } else { OV_TB(1); }
 #undef OV_TB
 #undef OV_TB2
     OV_LAUNCH_CHECK();
+    if (wg && wg_done) *wg_done = true;
     return ONTOVAE_OK;
 }
 
@@ -2206,30 +2267,46 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     if (refreshed && (rc = ov_side_join(s))) return rc;          // packed decoder weights ready
     if ((rc = ov_dec_forward_terms(s, true))) return rc;
     if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
-    if ((rc = ov_dec_backward(s))) return rc;
+    // weight gradient of the decoder: rows = nodes [0, C - L) (term rows), then the genes; entries = packed range [0, nnz)
+    const int n_term_rows = d.C - d.L;
+    const int wrows = n_term_rows + d.G;
+    const bool wcb = !(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES);
+    OvWgradArgs wa{};
+    int ride_rows = 0;
+    if (wcb) {
+        const int ncb = s.ldb / 32;
+        // a share of the gene rows, sized so that the riders finish about when the chain does (they run at half their
+        // usual occupancy there: one 1024-thread workgroup per CU next to the chain's LDS reservation)
+        ride_rows = std::min<int64_t>(d.G, ((int64_t)d.G * OV_RIDE_PCT / 100 + 31) / 32 * 32);
+        wa = OvWgradArgs{c->rowptr, c->colidx, s.ws.act, s.ws.d, s.ws.wpart, s.ws.wpart + (int64_t)ncb * d.nnz, (int64_t)d.nnz,
+                         wrows - ride_rows, ride_rows, wrows, 0, n_term_rows, d.C, s.ldb, ncb, (ride_rows + 31) / 32};
+    }
+    // the gene rows need only the gene layer's D rows: they ride in the backward chain's launch (on the CUs it leaves idle)
+    bool wgene_done = false;
+    const bool ride = wcb && !s.side && ride_rows > 0 && !(c->flags & ONTOVAE_FLAG_NO_RIDERS);
+    if ((rc = ov_dec_backward(s, ride ? &wa : nullptr, &wgene_done))) return rc;
     // fork: the decoder's weight gradients need nothing from the encoder backward, and vice versa
     if ((rc = ov_side_fork(s))) return rc;
     const hipStream_t sst = ov_side_stream(s);
     // decoder weight gradients (+ AdamW + clamp)
     {
-        const int n_term_rows = d.C - d.L;
-        const int nrows = n_term_rows + d.G;
+        const int nrows = wrows;
         float* G_ = c->Gr;
         OvProfScope prof(ONTOVAE_PHASE_DEC_WGRAD, sst);
-        if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
-            const int ncb = s.ldb / 32, ntiles = (nrows + 31) / 32;
-            float* part = s.ws.wpart;
-            float* bpart = part + (int64_t)ncb * d.nnz;
-            // the kernel's rows: nodes [0, C - L) then the genes; their entries are the packed range [0, nnz)
-            hipLaunchKernelGGL(ov_wgrad_cb_kernel, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act,
-                               s.ws.d, part, bpart, (int64_t)d.nnz, nrows, 0, n_term_rows, d.C, s.ldb, ncb, ntiles);
+        if (wcb) {
+            // what is left after the backward chain: the term rows (they need the chain's D), or all rows
+            OvWgradArgs wt = wa;
+            wt.row0 = 0;
+            wt.nrows_part = wgene_done ? nrows - ride_rows : nrows;
+            wt.ntiles = (wt.nrows_part + 31) / 32;
+            hipLaunchKernelGGL(ov_wgrad_cb_kernel, dim3(ov_cb_grid(wt.ncb, wt.ntiles)), dim3(256), 0, sst, wt);
             OV_LAUNCH_CHECK();
             const int blocks = (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 2048);
-            hipLaunchKernelGGL(ov_wgrad_finish_kernel, dim3(blocks), dim3(256), 0, sst, part, bpart, ncb, (int64_t)0, (int64_t)d.nnz,
-                               (int64_t)d.nnz, nrows, 0, n_term_rows, d.C, c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr,
-                               c->V ? c->V + lay.dec_vals : nullptr, G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias,
-                               c->M ? c->M + lay.dec_bias : nullptr, c->V ? c->V + lay.dec_bias : nullptr,
-                               G_ ? G_ + lay.dec_bias : nullptr, apply, adam);
+            hipLaunchKernelGGL(ov_wgrad_finish_kernel, dim3(blocks), dim3(256), 0, sst, wa.part, wa.bpart, wa.ncb, (int64_t)0,
+                               (int64_t)d.nnz, (int64_t)d.nnz, nrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,
+                               c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
+                               G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
+                               c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam);
             OV_LAUNCH_CHECK();
         } else {
             hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((nrows + 3) / 4), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act, s.ws.d,

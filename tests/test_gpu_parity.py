@@ -194,7 +194,7 @@ def test_train_vs_oracle_batch_sizes(B):
     check_params(hip_state(model), o.state_dict(), 3 * lr, rtol=2e-4, atol=2e-6, outliers=0.01)
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8, 16, 8 | 1])
 @pytest.mark.parametrize("B", [128, 200, 37])
 def test_gradients_vs_oracle(B, flags):
     """Raw gradients (apply_update=0 -> flat buffer) against the oracle's hand-written backward:
@@ -209,7 +209,9 @@ def test_gradients_vs_oracle(B, flags):
     rec, kl, loss, g = o.gradients(x, eps, 1e-4)
     model, _ = make_model(masks, 3, sd)
     e = model._engine
-    e.flags = flags          # 1: per-level launches, 2: row-per-wave gene layer (the general-purpose variants)
+    # 1: per-level launches, 2: row-per-wave gene layer (the general-purpose variants), 4: side stream,
+    # 8: wide gene-layer tiles instead of 32-column blocks, 16: no riders in the backward chain's launch
+    e.flags = flags
     e.invalidate()
     out = torch.zeros(3, device="cuda")
     e.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), 1e-4, None, out, apply_update=False)
