@@ -88,15 +88,17 @@ __device__ __forceinline__ f32x4 ov_ld_mc(const float* __restrict__ base, int64_
     return v;
 }
 
+// (bx, by, bz) = the workgroup's tile coordinates: blockIdx for a plain launch, remapped when the GEMM shares its
+// launch with riders (see ov_gemm_riders_kernel in ontovae_kernels.hip)
 template <int MT, int NT, int KW, int UK, bool A_KC, bool B_KC, bool VEC, int EPI>
-__global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
+__device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
     const int lane = ov_lane();
     const int wave = ov_wave_id();
     const int i = lane & 31, h = lane >> 5;
-    const int m0 = KW == 1 ? blockIdx.y * (64 * MT) + (wave >> 1) * (32 * MT) : blockIdx.y * (32 * MT);
-    const int n0 = KW == 1 ? blockIdx.x * (64 * NT) + (wave & 1) * (32 * NT) : blockIdx.x * (32 * NT);
-    const int kb0 = blockIdx.z * p.kchunk;
+    const int m0 = KW == 1 ? by * (64 * MT) + (wave >> 1) * (32 * MT) : by * (32 * MT);
+    const int n0 = KW == 1 ? bx * (64 * NT) + (wave & 1) * (32 * NT) : bx * (32 * NT);
+    const int kb0 = bz * p.kchunk;
     const int kb1 = min(p.K, kb0 + p.kchunk);
     int kbeg = kb0, kend = kb1;
     if (KW == 4) {   // contiguous quarters of the block's range, multiples of 8
@@ -363,12 +365,17 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
                     const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (m < p.M && n < p.N) {
                         const int64_t idx = (int64_t)m * p.ldc + n;
-                        if (EPI == OV_EPI_STORE) p.C[(int64_t)blockIdx.z * p.slab_stride + idx] = acc[mt][nt][r];
+                        if (EPI == OV_EPI_STORE) p.C[(int64_t)bz * p.slab_stride + idx] = acc[mt][nt][r];
                         else p.C[idx] = acc[mt][nt][r] + p.bias[m];
                     }
                 }
             }
         }
+}
+
+template <int MT, int NT, int KW, int UK, bool A_KC, bool B_KC, bool VEC, int EPI>
+__global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
+    ov_gemm_body<MT, NT, KW, UK, A_KC, B_KC, VEC, EPI>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 

@@ -429,15 +429,19 @@ __global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mul
 // (AdamW applied here, or stored when apply_update == 0), and the LAST block does the final reduction of the loss
 // partials (loss = rec + kl_coeff * kl, vae_model.py:129).
 struct OvLossArgs { const float* rec_part; int nrec; const float* kl_part; int nkl; float kc; float* out; };
-__global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mulv,
-                                                           const float* __restrict__ epsw, float* __restrict__ dmulv,
-                                                           int L, int B, int ldb, float kc, float z_drop, uint64_t seed,
-                                                           uint64_t rng_off, float* __restrict__ bh, float* __restrict__ mbh,
-                                                           float* __restrict__ vbh, float* __restrict__ gbh, int apply_update,
-                                                           OvAdam adam, const OvLossArgs la) {
+struct OvLatentArgs {
+    const float* dz; const float* mulv; const float* epsw; float* dmulv;
+    int L, B, ldb; float kc, z_drop; uint64_t seed, rng_off;
+    float* bh; float* mbh; float* vbh; float* gbh; int apply_update; OvAdam adam;
+    OvLossArgs la;
+    int nblocks;          // (L + 3) / 4 feature blocks + 1 loss block
+};
+// block: this workgroup's number inside the latent part, in [0, nblocks)
+__device__ __forceinline__ void ov_latent_bwd_body(const OvLatentArgs& a, const int block) {
     const int lane = ov_lane();
-    if (blockIdx.x == gridDim.x - 1) {
+    if (block == a.nblocks - 1) {
         __shared__ double red[2][4];
+        const OvLossArgs& la = a.la;
         double r = 0.0, k = 0.0;
         for (int i = threadIdx.x; i < la.nrec; i += 256) r += (double)la.rec_part[i];
         for (int i = threadIdx.x; i < la.nkl; i += 256) k += (double)la.kl_part[i];
@@ -454,7 +458,8 @@ __global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const float* __restr
         }
         return;
     }
-    const int l = blockIdx.x * 4 + ov_wave_id();
+    const int L = a.L, B = a.B, ldb = a.ldb;
+    const int l = block * 4 + ov_wave_id();
     if (l >= L) return;
     const int64_t n = (int64_t)L * ldb;
     float smu = 0.f, slv = 0.f;
@@ -462,16 +467,16 @@ __global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const float* __restr
         const int64_t idx = (int64_t)l * ldb + b;
         float dmu = 0.f, dlv = 0.f;
         if (b < B) {
-            const float mu = mulv[idx], lv = mulv[n + idx], g = dz[idx], e = epsw[idx];
-            dmu = g + kc * mu;
-            dlv = g * e * 0.5f * expf(0.5f * lv) + 0.5f * kc * (expf(lv) - 1.f);
-            if (z_drop > 0.f) {
-                dmu *= ov_dropout_scale(z_drop, seed, rng_off, OV_RNG_ZDROP_MU, (uint64_t)l * 0x100000000ull + b);
-                dlv *= ov_dropout_scale(z_drop, seed, rng_off, OV_RNG_ZDROP_LV, (uint64_t)l * 0x100000000ull + b);
+            const float mu = a.mulv[idx], lv = a.mulv[n + idx], g = a.dz[idx], e = a.epsw[idx];
+            dmu = g + a.kc * mu;
+            dlv = g * e * 0.5f * expf(0.5f * lv) + 0.5f * a.kc * (expf(lv) - 1.f);
+            if (a.z_drop > 0.f) {
+                dmu *= ov_dropout_scale(a.z_drop, a.seed, a.rng_off, OV_RNG_ZDROP_MU, (uint64_t)l * 0x100000000ull + b);
+                dlv *= ov_dropout_scale(a.z_drop, a.seed, a.rng_off, OV_RNG_ZDROP_LV, (uint64_t)l * 0x100000000ull + b);
             }
         }
-        dmulv[idx] = dmu;
-        dmulv[n + idx] = dlv;
+        a.dmulv[idx] = dmu;
+        a.dmulv[n + idx] = dlv;
         smu += dmu;
         slv += dlv;
     }
@@ -480,12 +485,12 @@ __global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const float* __restr
     if (lane < 2) {                     // lane 0: bias of mu[l]; lane 1: bias of log_var[l]
         const int r = lane == 0 ? l : L + l;
         const float g = lane == 0 ? smu : slv;
-        if (apply_update) {
-            float ww = bh[r], mm = mbh[r], vv = vbh[r];
-            ov_adamw(ww, mm, vv, g, adam, false);
-            bh[r] = ww; mbh[r] = mm; vbh[r] = vv;
+        if (a.apply_update) {
+            float ww = a.bh[r], mm = a.mbh[r], vv = a.vbh[r];
+            ov_adamw(ww, mm, vv, g, a.adam, false);
+            a.bh[r] = ww; a.mbh[r] = mm; a.vbh[r] = vv;
         } else {
-            gbh[r] = g;
+            a.gbh[r] = g;
         }
     }
 }
@@ -1418,36 +1423,61 @@ __global__ __launch_bounds__(1024) void ov_chain_bwd_wgrad_kernel(const OvChainA
 
 // g_k = sum over column blocks of part[cb][k] (fixed order), then AdamW + clamp(0) (vae_model.py:172-176) or the
 // plain gradient; the same for the biases of the rows.
-__global__ __launch_bounds__(256) void ov_wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int ncb,
-                                                             int64_t k_begin, int64_t k_end, int64_t nnz, int nrows,
-                                                             int first_term_node, int n_term_rows, int C,
-                                                             float* __restrict__ vals, float* __restrict__ mvals, float* __restrict__ vvals,
-                                                             float* __restrict__ gvals, float* __restrict__ bias, float* __restrict__ mbias,
-                                                             float* __restrict__ vbias, float* __restrict__ gbias, int apply_update, OvAdam adam) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t k = k_begin + (int64_t)blockIdx.x * 256 + threadIdx.x; k < k_end; k += stride) {
+struct OvFinishArgs {
+    const float* part; const float* bpart; int ncb;
+    int64_t nnz; int nrows, first_term_node, n_term_rows, C;
+    float* vals; float* mvals; float* vvals; float* gvals;
+    float* bias; float* mbias; float* vbias; float* gbias;
+    int apply_update; OvAdam adam;
+};
+// first / stride: this thread's number and the thread count of the finish part
+__device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, const int64_t first, const int64_t stride) {
+    for (int64_t k = first; k < a.nnz; k += stride) {
         float g = 0.f;
-        for (int cb = 0; cb < ncb; ++cb) g += part[(int64_t)cb * nnz + k];
-        if (apply_update) {
-            float w = vals[k], m = mvals[k], v = vvals[k];
-            ov_adamw(w, m, v, g, adam, true);
-            vals[k] = w; mvals[k] = m; vvals[k] = v;
+        for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
+        if (a.apply_update) {
+            float w = a.vals[k], m = a.mvals[k], v = a.vvals[k];
+            ov_adamw(w, m, v, g, a.adam, true);
+            a.vals[k] = w; a.mvals[k] = m; a.vvals[k] = v;
         } else {
-            gvals[k] = g;
+            a.gvals[k] = g;
         }
     }
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nrows; r += stride) {
+    for (int64_t r = first; r < a.nrows; r += stride) {
         float g = 0.f;
-        for (int cb = 0; cb < ncb; ++cb) g += bpart[(int64_t)cb * nrows + r];
-        const int node = r < n_term_rows ? first_term_node + (int)r : C + ((int)r - n_term_rows);
-        if (apply_update) {
-            float w = bias[node], m = mbias[node], v = vbias[node];
-            ov_adamw(w, m, v, g, adam, false);
-            bias[node] = w; mbias[node] = m; vbias[node] = v;
+        for (int cb = 0; cb < a.ncb; ++cb) g += a.bpart[(int64_t)cb * a.nrows + r];
+        const int node = r < a.n_term_rows ? a.first_term_node + (int)r : a.C + ((int)r - a.n_term_rows);
+        if (a.apply_update) {
+            float w = a.bias[node], m = a.mbias[node], v = a.vbias[node];
+            ov_adamw(w, m, v, g, a.adam, false);
+            a.bias[node] = w; a.mbias[node] = m; a.vbias[node] = v;
         } else {
-            gbias[node] = g;
+            a.gbias[node] = g;
         }
     }
+}
+__global__ __launch_bounds__(256) void ov_wgrad_finish_kernel(const OvFinishArgs a) {
+    ov_wgrad_finish_body(a, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+
+// Two launches of the backward pass that carry unrelated, independent work of the decoder's weight update so that it
+// costs no launch of its own (all parts are 256-thread workgroups):
+//   latent backward (a few dozen workgroups)  +  weight-gradient partials of the rows the backward chain finished
+//   da = Wh^T dmulv (split-K GEMM)             +  the finish pass over the partials (AdamW + clamp)
+__global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const OvLatentArgs la, const OvWgradArgs wa, int wteams) {
+    __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
+    if ((int)blockIdx.x < la.nblocks) { ov_latent_bwd_body(la, blockIdx.x); return; }
+    if ((int)blockIdx.x - la.nblocks < wteams) ov_wgrad_cb_body(wa, (int)blockIdx.x - la.nblocks, threadIdx.x, sh_k0, sh_len, sh_ord);
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void ov_da_gemm_kernel(const OvGemm g, int gx, int gy, int gz, const OvFinishArgs fa, int fblocks) {
+    const int b = blockIdx.x;
+    const int ngemm = gx * gy * gz;
+    if (b < ngemm) {
+        ov_gemm_body<1, 1, 4, 4, false, false, VEC, OV_EPI_STORE>(g, b % gx, (b / gx) % gy, b / (gx * gy));
+        return;
+    }
+    ov_wgrad_finish_body(fa, (int64_t)(b - ngemm) * 256 + threadIdx.x, (int64_t)fblocks * 256);
 }
 
 // Weight gradient at mask positions only (SDDMM) + fused AdamW + clamp(0), one wave per row node:
@@ -2288,46 +2318,52 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     // fork: the decoder's weight gradients need nothing from the encoder backward, and vice versa
     if ((rc = ov_side_fork(s))) return rc;
     const hipStream_t sst = ov_side_stream(s);
-    // decoder weight gradients (+ AdamW + clamp)
-    {
-        const int nrows = wrows;
-        float* G_ = c->Gr;
+    // decoder weight gradients (+ AdamW + clamp): partials of the rows the chain launch did not carry, then the finish
+    // pass.  On the single-stream path both ride in the next two launches (ov_latent_bwd_kernel, ov_da_gemm_kernel).
+    float* G_ = c->Gr;
+    OvWgradArgs wt = wa;
+    OvFinishArgs fa{};
+    int wteams = 0, fblocks = 0;
+    const bool riders2 = wcb && !s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS);
+    if (wcb) {
+        wt.row0 = 0;
+        wt.nrows_part = wgene_done ? wrows - ride_rows : wrows;
+        wt.ntiles = (wt.nrows_part + 31) / 32;
+        wteams = ov_cb_grid(wt.ncb, wt.ntiles);
+        fblocks = (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 2048);
+        fa = OvFinishArgs{wa.part, wa.bpart, wa.ncb, (int64_t)d.nnz, wrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,
+                          c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
+                          G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
+                          c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam};
+    }
+    if (!riders2) {
         OvProfScope prof(ONTOVAE_PHASE_DEC_WGRAD, sst);
         if (wcb) {
-            // what is left after the backward chain: the term rows (they need the chain's D), or all rows
-            OvWgradArgs wt = wa;
-            wt.row0 = 0;
-            wt.nrows_part = wgene_done ? nrows - ride_rows : nrows;
-            wt.ntiles = (wt.nrows_part + 31) / 32;
-            hipLaunchKernelGGL(ov_wgrad_cb_kernel, dim3(ov_cb_grid(wt.ncb, wt.ntiles)), dim3(256), 0, sst, wt);
+            hipLaunchKernelGGL(ov_wgrad_cb_kernel, dim3(wteams), dim3(256), 0, sst, wt);
             OV_LAUNCH_CHECK();
-            const int blocks = (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 2048);
-            hipLaunchKernelGGL(ov_wgrad_finish_kernel, dim3(blocks), dim3(256), 0, sst, wa.part, wa.bpart, wa.ncb, (int64_t)0,
-                               (int64_t)d.nnz, (int64_t)d.nnz, nrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,
-                               c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
-                               G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
-                               c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam);
+            hipLaunchKernelGGL(ov_wgrad_finish_kernel, dim3(fblocks), dim3(256), 0, sst, fa);
             OV_LAUNCH_CHECK();
         } else {
-            hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((nrows + 3) / 4), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act, s.ws.d,
+            hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((wrows + 3) / 4), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act, s.ws.d,
                                c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                                G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
-                               c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, nrows, 0, n_term_rows, d.C, s.ldb,
+                               c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, wrows, 0, n_term_rows, d.C, s.ldb,
                                apply, adam);
             OV_LAUNCH_CHECK();
         }
     }
-    // latent backward (+ head bias gradient / AdamW, + final reduction of the loss partials)
+    // latent backward (+ head bias gradient / AdamW, + final reduction of the loss partials) [+ weight-gradient partials]
     {
-        OvLossArgs la{s.ws.rec_part, ov_nrec(s), s.ws.kl_part, nkl, kc, loss_out};
+        OvLatentArgs la{s.ws.d + (int64_t)(d.C - d.L) * s.ldb, s.ws.mulv, s.ws.epsw, s.ws.dmulv, d.L, s.B, s.ldb, kc, c->z_drop,
+                        c->seed, rng_off, c->P + lay.bh, c->M ? c->M + lay.bh : nullptr, c->V ? c->V + lay.bh : nullptr,
+                        c->Gr ? c->Gr + lay.bh : nullptr, apply, adam,
+                        OvLossArgs{s.ws.rec_part, ov_nrec(s), s.ws.kl_part, nkl, kc, loss_out}, (d.L + 3) / 4 + 1};
         OvProfScope prof(ONTOVAE_PHASE_LATENT_BWD, s.st);
-        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3((d.L + 3) / 4 + 1), dim3(256), 0, s.st, s.ws.d + (int64_t)(d.C - d.L) * s.ldb,
-                           s.ws.mulv, s.ws.epsw, s.ws.dmulv, d.L, s.B, s.ldb, kc, c->z_drop, c->seed, rng_off, c->P + lay.bh,
-                           c->M ? c->M + lay.bh : nullptr, c->V ? c->V + lay.bh : nullptr, c->Gr ? c->Gr + lay.bh : nullptr, apply,
-                           adam, la);
+        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(la.nblocks + (riders2 ? wteams : 0)), dim3(256), 0, s.st, la, wt,
+                           riders2 ? wteams : 0);
         OV_LAUNCH_CHECK();
     }
-    // da = Wh^T dmulv  (before Wh is updated)
+    // da = Wh^T dmulv  (before Wh is updated) [+ finish pass of the decoder weight update]
     int da_S = 1;
     {
         OvGemm g{};
@@ -2341,7 +2377,11 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         da_S = (2 * d.L + kchunk - 1) / kchunk;
         g.C = da_S > 1 ? s.ws.slab : s.ws.da; g.ldc = s.ldb; g.slab_stride = one; g.kchunk = kchunk;
         OvProfScope prof(ONTOVAE_PHASE_DA_GEMM, s.st);
-        if ((rc = ov_launch_gemm<1, 1, 4, 4, false, false, OV_EPI_STORE>(g, da_S, false, s.st))) return rc;
+        const int gx = (g.N + 31) / 32, gy = (g.M + 31) / 32;
+        const size_t lds = (size_t)2 * 16 * 64 * sizeof(float);        // KW == 4 reduction area of a 1 x 1 tile
+        hipLaunchKernelGGL((ov_da_gemm_kernel<false>), dim3(gx * gy * da_S + (riders2 ? fblocks : 0)), dim3(256), lds, s.st, g, gx, gy,
+                           da_S, fa, riders2 ? fblocks : 0);
+        OV_LAUNCH_CHECK();
     }
     // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv): side stream, after da has read Wh
     const bool dwh_main = (c->flags & 64u) != 0;
