@@ -280,19 +280,27 @@ __global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict_
 // mode 1: fused single GPU (local sums are global), then AdamW on gamma, beta, b0 or grads to Gr
 // mode 2: DP phase 1 tail: write dy into dh buffer and local sums to bwd_local/bwd_stats
 // mode 3: DP phase 2 head: read dy from dh, global sums from bwd_stats; grads (LOCAL sums) to Gr
-__global__ __launch_bounds__(256) void ov_bn_bwd_kernel(const float* __restrict__ da, const float* __restrict__ a,
-                                                       const float* __restrict__ xhat, const float* __restrict__ invstd,
-                                                       float* __restrict__ P_gamma, float* __restrict__ P_beta,
-                                                       float* __restrict__ P_b0, float* __restrict__ M_gamma,
-                                                       float* __restrict__ M_beta, float* __restrict__ M_b0,
-                                                       float* __restrict__ V_gamma, float* __restrict__ V_beta,
-                                                       float* __restrict__ V_b0, float* __restrict__ G_gamma,
-                                                       float* __restrict__ G_beta, float* __restrict__ G_b0,
-                                                       float* __restrict__ dh, float* __restrict__ bwd_local,
-                                                       float* __restrict__ bwd_stats, int L, int B, int Bglobal, int ldb,
-                                                       int mode, int apply_update, OvAdam adam, float drop, uint64_t seed,
-                                                       uint64_t rng_off, int daS, int64_t dastride) {
-    const int l = blockIdx.x * 4 + ov_wave_id();
+struct OvBnBwdArgs {
+    const float* da; const float* a; const float* xhat; const float* invstd;
+    float* P_gamma; float* P_beta; float* P_b0; float* M_gamma; float* M_beta; float* M_b0;
+    float* V_gamma; float* V_beta; float* V_b0; float* G_gamma; float* G_beta; float* G_b0;
+    float* dh; float* bwd_local; float* bwd_stats;
+    int L, B, Bglobal, ldb, mode, apply_update; OvAdam adam; float drop; uint64_t seed, rng_off;
+    int daS; int64_t dastride;
+};
+// block: this workgroup's number inside the BatchNorm part, 4 features per workgroup
+__device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int block) {
+    const float* __restrict__ da = q.da; const float* __restrict__ a = q.a; const float* __restrict__ xhat = q.xhat;
+    const float* __restrict__ invstd = q.invstd;
+    float* __restrict__ P_gamma = q.P_gamma; float* __restrict__ P_beta = q.P_beta; float* __restrict__ P_b0 = q.P_b0;
+    float* __restrict__ M_gamma = q.M_gamma; float* __restrict__ M_beta = q.M_beta; float* __restrict__ M_b0 = q.M_b0;
+    float* __restrict__ V_gamma = q.V_gamma; float* __restrict__ V_beta = q.V_beta; float* __restrict__ V_b0 = q.V_b0;
+    float* __restrict__ G_gamma = q.G_gamma; float* __restrict__ G_beta = q.G_beta; float* __restrict__ G_b0 = q.G_b0;
+    float* __restrict__ dh = q.dh; float* __restrict__ bwd_local = q.bwd_local; float* __restrict__ bwd_stats = q.bwd_stats;
+    const int L = q.L, B = q.B, Bglobal = q.Bglobal, ldb = q.ldb, mode = q.mode, apply_update = q.apply_update;
+    const OvAdam adam = q.adam; const float drop = q.drop; const uint64_t seed = q.seed, rng_off = q.rng_off;
+    const int daS = q.daS; const int64_t dastride = q.dastride;
+    const int l = block * 4 + ov_wave_id();
     if (l >= L) return;
     const int lane = ov_lane();
     const int64_t ro = (int64_t)l * ldb;
@@ -349,6 +357,8 @@ __global__ __launch_bounds__(256) void ov_bn_bwd_kernel(const float* __restrict_
         }
     }
 }
+
+__global__ __launch_bounds__(256) void ov_bn_bwd_kernel(const OvBnBwdArgs q) { ov_bn_bwd_body(q, blockIdx.x); }
 
 // =================================================================================================
 // Latent: z_drop dropout on the heads, reparameterisation, KL
@@ -1479,6 +1489,16 @@ __global__ __launch_bounds__(256) void ov_da_gemm_kernel(const OvGemm g, int gx,
     }
     ov_wgrad_finish_body(fa, (int64_t)(b - ngemm) * 256 + threadIdx.x, (int64_t)fblocks * 256);
 }
+// dWh = dmulv a^T (+ AdamW) and the BatchNorm backward are independent once da exists: one launch
+template <int EPI>
+__global__ __launch_bounds__(256) void ov_dwh_bn_kernel(const OvGemm g, int gx, int gy, const OvBnBwdArgs bn) {
+    const int b = blockIdx.x;
+    if (b < gx * gy) {
+        ov_gemm_body<1, 1, 4, 2, true, true, true, EPI>(g, b % gx, b / gx, 0);
+        return;
+    }
+    ov_bn_bwd_body(bn, b - gx * gy);
+}
 
 // Weight gradient at mask positions only (SDDMM) + fused AdamW + clamp(0), one wave per row node:
 //   g_k = sum_b D[n, b] * ACT[colidx[k], b];   gb = sum_b D[n, b]
@@ -2383,36 +2403,44 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                            da_S, fa, riders2 ? fblocks : 0);
         OV_LAUNCH_CHECK();
     }
-    // dWh = dmulv a^T (+ AdamW), dbh = rowsum(dmulv): side stream, after da has read Wh
+    // dWh = dmulv a^T (+ AdamW) and the BatchNorm backward (dh; AdamW of gamma, beta, b0): independent, one launch on
+    // the single-stream path.  (dbh is done by the latent backward launch.)
+    OvGemm gw{};
+    gw.M = 2 * d.L; gw.N = d.L; gw.K = s.B;
+    gw.A = s.ws.dmulv; gw.lda = s.ldb;
+    gw.B = s.ws.a; gw.ldb = s.ldb;
+    gw.ldc = d.L; gw.kchunk = (s.B + 31) / 32 * 32;
+    gw.adam = adam;
+    if (apply) { gw.C = c->P + lay.Wh; gw.Pm = c->M + lay.Wh; gw.Pv = c->V + lay.Wh; }
+    else gw.C = c->Gr + lay.Wh;
+    float* Gr = c->Gr;
+    const OvBnBwdArgs bn{da_S > 1 ? s.ws.slab : s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd, c->P + lay.gamma, c->P + lay.beta,
+                         c->P + lay.b0, c->M ? c->M + lay.gamma : nullptr, c->M ? c->M + lay.beta : nullptr,
+                         c->M ? c->M + lay.b0 : nullptr, c->V ? c->V + lay.gamma : nullptr, c->V ? c->V + lay.beta : nullptr,
+                         c->V ? c->V + lay.b0 : nullptr, Gr ? Gr + lay.gamma : nullptr, Gr ? Gr + lay.beta : nullptr,
+                         Gr ? Gr + lay.b0 : nullptr, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, s.B, Bglobal, s.ldb, bn_mode,
+                         apply, adam, c->drop, c->seed, rng_off, da_S, (int64_t)d.L * s.ldb};
+    const int bn_blocks = (d.L + 3) / 4;
+    if (!s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS)) {
+        OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
+        const int gx = (gw.N + 31) / 32, gy = (gw.M + 31) / 32;
+        const size_t lds = (size_t)2 * 16 * 64 * sizeof(float);
+        if (apply) hipLaunchKernelGGL((ov_dwh_bn_kernel<OV_EPI_ADAMW>), dim3(gx * gy + bn_blocks), dim3(256), lds, s.st, gw, gx, gy, bn);
+        else hipLaunchKernelGGL((ov_dwh_bn_kernel<OV_EPI_STORE>), dim3(gx * gy + bn_blocks), dim3(256), lds, s.st, gw, gx, gy, bn);
+        OV_LAUNCH_CHECK();
+        return ONTOVAE_OK;
+    }
     const bool dwh_main = (c->flags & 64u) != 0;
     if (!dwh_main && (rc = ov_side_sync_mid(s))) return rc;
     {
-        const hipStream_t sst = dwh_main ? s.st : ov_side_stream(s);
-        OvGemm g{};
-        g.M = 2 * d.L; g.N = d.L; g.K = s.B;
-        g.A = s.ws.dmulv; g.lda = s.ldb;
-        g.B = s.ws.a; g.ldb = s.ldb;
-        g.ldc = d.L; g.kchunk = (s.B + 31) / 32 * 32;
-        g.adam = adam;
-        OvProfScope prof(ONTOVAE_PHASE_DWH, sst);
-        if (apply) {
-            g.C = c->P + lay.Wh; g.Pm = c->M + lay.Wh; g.Pv = c->V + lay.Wh;
-            if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_ADAMW>(g, 1, true, sst))) return rc;
-        } else {
-            g.C = c->Gr + lay.Wh;
-            if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_STORE>(g, 1, true, sst))) return rc;
-        }
+        const hipStream_t wst = dwh_main ? s.st : ov_side_stream(s);
+        OvProfScope prof(ONTOVAE_PHASE_DWH, wst);
+        if (apply) { if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_ADAMW>(gw, 1, true, wst))) return rc; }
+        else { if ((rc = ov_launch_gemm<1, 1, 4, 2, true, true, OV_EPI_STORE>(gw, 1, true, wst))) return rc; }
     }
-    // BN backward
     {
-        float* Gr = c->Gr;
         OvProfScope prof(ONTOVAE_PHASE_BN_BWD, s.st);
-        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, da_S > 1 ? s.ws.slab : s.ws.da, s.ws.a, s.ws.xhat,
-                           s.ws.bn_invstd, c->P + lay.gamma, c->P + lay.beta, c->P + lay.b0, c->M ? c->M + lay.gamma : nullptr,
-                           c->M ? c->M + lay.beta : nullptr, c->M ? c->M + lay.b0 : nullptr, c->V ? c->V + lay.gamma : nullptr,
-                           c->V ? c->V + lay.beta : nullptr, c->V ? c->V + lay.b0 : nullptr, Gr ? Gr + lay.gamma : nullptr,
-                           Gr ? Gr + lay.beta : nullptr, Gr ? Gr + lay.b0 : nullptr, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L,
-                           s.B, Bglobal, s.ldb, bn_mode, apply, adam, c->drop, c->seed, rng_off, da_S, (int64_t)d.L * s.ldb);
+        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3(bn_blocks), dim3(256), 0, s.st, bn);
         OV_LAUNCH_CHECK();
     }
     return ONTOVAE_OK;
@@ -2498,10 +2526,11 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
         const ontovae_dims_t& d = ctx->dims;
         const ontovae_layout_t& lay = ctx->lay;
         OvAdam adam{};
-        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd,
-                           ctx->P + lay.gamma, ctx->P + lay.beta, ctx->P + lay.b0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           ctx->Gr + lay.gamma, ctx->Gr + lay.beta, ctx->Gr + lay.b0, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, B,
-                           B_global, s.ldb, 3, 0, adam, ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0);
+        const OvBnBwdArgs bn{s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd, ctx->P + lay.gamma, ctx->P + lay.beta, ctx->P + lay.b0,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->Gr + lay.gamma, ctx->Gr + lay.beta,
+                             ctx->Gr + lay.b0, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, B, B_global, s.ldb, 3, 0, adam,
+                             ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0};
+        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, bn);
         OV_LAUNCH_CHECK();
         return ov_dw0(s, nullptr, 0);
     }
