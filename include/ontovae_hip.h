@@ -296,16 +296,16 @@ enum {
     ONTOVAE_PHASE_ENC_GEMM = 0,      /* x W0^T (split-K MFMA)                       */
     ONTOVAE_PHASE_BN_FWD = 1,        /* split-K combine + BatchNorm + ReLU          */
     ONTOVAE_PHASE_HEADS = 2,         /* mu / log_var heads                          */
-    ONTOVAE_PHASE_REPARAM = 3,       /* z_drop, reparameterisation, KL              */
+    ONTOVAE_PHASE_REPARAM = 3,       /* head slabs + bias, z_drop, reparameterisation, KL (+ packed-weight refresh) */
     ONTOVAE_PHASE_DEC_FWD_TERMS = 4, /* term levels of the decoder (K-1 launches)   */
     ONTOVAE_PHASE_DEC_FWD_GENE = 5,  /* gene layer + ELBO epilogue                  */
-    ONTOVAE_PHASE_DEC_BWD = 6,       /* decoder backward data, term levels          */
-    ONTOVAE_PHASE_LOSS = 7,          /* loss partial reduction                      */
-    ONTOVAE_PHASE_DEC_WGRAD = 8,     /* decoder weight gradient + AdamW + clamp     */
-    ONTOVAE_PHASE_LATENT_BWD = 9,    /* d mu, d log_var                             */
-    ONTOVAE_PHASE_DA_GEMM = 10,      /* heads backward data                         */
-    ONTOVAE_PHASE_DWH = 11,          /* heads weight gradient + AdamW               */
-    ONTOVAE_PHASE_BN_BWD = 12,       /* BatchNorm backward + AdamW of gamma/beta/b0 */
+    ONTOVAE_PHASE_DEC_BWD = 6,       /* decoder backward data, term levels (+ riders: dW of the gene rows) */
+    ONTOVAE_PHASE_LOSS = 7,          /* loss partial reduction (own launch in eval only) */
+    ONTOVAE_PHASE_DEC_WGRAD = 8,     /* decoder weight gradient + AdamW + clamp (own launches only without riders) */
+    ONTOVAE_PHASE_LATENT_BWD = 9,    /* d mu, d log_var, dbh, loss (+ riders: dW partials of the term rows) */
+    ONTOVAE_PHASE_DA_GEMM = 10,      /* heads backward data (+ riders: decoder AdamW finish pass) */
+    ONTOVAE_PHASE_DWH = 11,          /* heads weight gradient + AdamW (+ BatchNorm backward in the same launch) */
+    ONTOVAE_PHASE_BN_BWD = 12,       /* BatchNorm backward + AdamW of gamma/beta/b0 (own launch only without riders / DP) */
     ONTOVAE_PHASE_DW0 = 13,          /* dW0 = dh x (MFMA) + fused AdamW             */
     ONTOVAE_PHASE_DEC_BWD_GENE = 14, /* decoder backward data, gene layer           */
     ONTOVAE_PHASE_SELL_REFRESH = 15, /* packed term-level weight copies <- params   */

@@ -410,8 +410,17 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
     const int wave = ov_wave_id();
     const int i = lane & 31, h = lane >> 5;
     const int wm = WM == 4 ? wave : 0, wn = WN == 4 ? wave : 0;
-    const int m0 = blockIdx.y * RA, n0 = blockIdx.x * RB;
-    const int kb0 = blockIdx.z * p.kchunk;
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  The row tiles (y) of one K slab (z) read the same
+    // B tile, so they are renumbered to share an XCD (and its L2): linear id = xcd + 8 j  ->  z = xcd + 8 (j / ny), y = j % ny.
+    int by = blockIdx.y, bz = blockIdx.z;
+    if (gridDim.x == 1 && gridDim.z % 8 == 0) {
+        const int id = blockIdx.y + gridDim.y * blockIdx.z, ny = gridDim.y;
+        const int xcd = id & 7, j = id >> 3;
+        bz = xcd + 8 * (j / ny);
+        by = j % ny;
+    }
+    const int m0 = by * RA, n0 = blockIdx.x * RB;
+    const int kb0 = bz * p.kchunk;
     const int kb1 = min(p.K, kb0 + p.kchunk);
     if (!B_KC) {
         for (int t = tid; t < kb1 - kb0; t += 256) rows[t] = p.bgather ? p.bgather[kb0 + t] : kb0 + t;
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < p.M && n < p.N) p.C[(int64_t)blockIdx.z * p.slab_stride + (int64_t)m * p.ldc + n] = acc[mt][r];
+                if (m < p.M && n < p.N) p.C[(int64_t)bz * p.slab_stride + (int64_t)m * p.ldc + n] = acc[mt][r];
             }
         }
     }

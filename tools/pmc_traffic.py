@@ -1,0 +1,45 @@
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one run each, no trace flags) into
+profiles/pmc_traffic.json: HBM-side bytes per launch for every kernel and for bench.py's phases.
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KB; on gfx950
+FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRITE_SIZE is taken as is.
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
+"""
+import csv, collections, json, sys
+
+PHASE_OF = {"ov_dw0_kernel": "dw0", "ov_gemm_lds_kernel": "enc_gemm", "ov_gene_cb_kernel": "dec_fwd_gene",
+            "ov_bwd_gene_cb_kernel": "dec_bwd_gene", "ov_chain_bwd_wgrad_kernel": "dec_bwd",
+            "ov_dec_chain_kernel": "dec_fwd_terms", "ov_latent_bwd_kernel": "latent_bwd", "ov_da_gemm_kernel": "da_gemm",
+            "ov_dwh_bn_kernel": "dwh", "ov_bn_fwd_kernel": "bn_fwd", "ov_reparam_kernel": "reparam"}
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    # last launches only: the first ones include cold caches
+    return {k: sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1) for k, v in acc.items()}
+
+
+def main():
+    f = per_kernel(sys.argv[1], "FETCH_SIZE")
+    w = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"_note": "bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950 correction: FETCH_SIZE doubled); "
+                    "mean of the second half of the launches of a 6-step run; Infinity-Cache hits are counted",
+           "kernels": {}}
+    for k in sorted(set(f) | set(w)):
+        if "ov_" not in k:
+            continue
+        rd, wr = 2 * f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
+        short = k.split("(")[0].replace("void ", "")
+        out["kernels"][short] = {"read_bytes": rd, "write_bytes": wr, "bytes": rd + wr}
+        for stem, phase in PHASE_OF.items():
+            if short.startswith(stem) and phase not in out:
+                out[phase] = rd + wr
+    json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print(f"{k[:60]:60s} read {v['read_bytes']/1e6:8.1f} MB write {v['write_bytes']/1e6:8.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
