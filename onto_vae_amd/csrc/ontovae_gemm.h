@@ -49,6 +49,10 @@ struct OvGemm {
     float* Pv;
     OvAdam adam;
     int dbg;              // measurement only: 1 = skip the main loop, 2 = skip the epilogue
+    // ov_dw0_multi_kernel only: A given as rank blocks (data parallel, all-gathered dh): k = r * a_blm + j lives at
+    // A[r * a_rstride + m * lda + j]; a_blm == 0: plain A[m * lda + k]
+    int a_blm;
+    int64_t a_rstride;
 };
 
 template <bool FULL, bool VEC>
@@ -759,6 +763,142 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
         for (int q = 0; q < 16; ++q) out[q] = probe_t[q];
     }
 #endif
+}
+
+// The same product for any batch size (K > 128: larger single-GPU batches, and the data-parallel step where every
+// rank forms dW0 of the GLOBAL batch from the all-gathered dh): K is walked in chunks of 128 with the four tile
+// accumulators of the wave held across chunks, then the AdamW pass over the tiles with the same request ring.
+// MFMA-bound from K of a few hundred on (2 L G K flops), so the chunk prologues are not pipelined.
+template <int NW, int EPI>
+__global__ __launch_bounds__(64 * NW) void ov_dw0_multi_kernel(const OvGemm p, int njobs) {
+    constexpr int LT = 4, RA = 32 * LT, KC = 128, LDA = KC + 4;
+    extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
+    float* As = ov_gemm_lds;                                             // [RA][LDA]
+    int32_t* rows = reinterpret_cast<int32_t*>(ov_gemm_lds + RA * LDA);  // [KC]
+    const int tid = threadIdx.x;
+    const int lane = ov_lane();
+    const int wave = ov_wave_id();
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const int job = (b >> 3) % njobs;
+    const int gx = (b / (8 * njobs)) * 8 + (b & 7);
+    const int m0 = job * RA;
+    const int n0 = (gx * NW + wave) * 32;
+    const bool wave_on = n0 < p.N;
+    const uint32_t row_bytes = (uint32_t)p.ldc * 4u;
+    const int32_t lane_off = n0 + i < p.N ? (int32_t)(((uint32_t)(4 * h) * (uint32_t)p.ldc + (uint32_t)(n0 + i)) * 4u) : (int32_t)0x80000000u;
+    auto row_rsrc = [&](const float* base, int mb, int r) {
+        const int row = mb + (r & 3) + 8 * (r >> 2);
+        const uint32_t ro = (uint32_t)row * row_bytes;
+        return ov_buf_rsrc(reinterpret_cast<const char*>(base) + ro, (uint32_t)max(p.M - row, 0) * row_bytes);
+    };
+    const int blm = p.a_blm > 0 ? p.a_blm : 0x40000000;
+    const float* xcol = p.B + min(n0 + i, p.N - 1);
+
+    f32x16 acc[LT];
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[lt][r] = 0.f;
+
+    constexpr int SU = RA * (KC / 4) / (64 * NW);
+#pragma unroll 1
+    for (int kc = 0; kc < p.K; kc += KC) {
+        f32x4 sv[SU];
+#pragma unroll
+        for (int q = 0; q < SU; ++q) {
+            const int u = tid + q * 64 * NW;
+            const int r = u / (KC / 4), k = kc + 4 * (u % (KC / 4));
+            const int m = m0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < p.M && k < p.K) {
+                const int rb = k / blm, j = k - rb * blm;
+                const float* src = p.A + (int64_t)rb * p.a_rstride + (int64_t)m * p.lda + j;
+                if (k + 3 < p.K && j + 3 < blm) v = *reinterpret_cast<const f32x4*>(src);
+                else {                          // the last columns of the batch (never across a rank block: a_blm % 4 == 0)
+                    v.x = src[0];
+                    v.y = k + 1 < p.K ? src[1] : 0.f;
+                    v.z = k + 2 < p.K ? src[2] : 0.f;
+                }
+            }
+            sv[q] = v;
+        }
+        for (int t = tid; t < KC; t += 64 * NW) {
+            const int tt = min(kc + t, p.K - 1);
+            rows[t] = p.bgather ? p.bgather[tt] : tt;
+        }
+        __syncthreads();
+        float xb[KC / 2];
+        if (wave_on) {
+#pragma unroll
+            for (int s = 0; s < KC / 8; ++s) {
+                const int4 rr = *reinterpret_cast<const int4*>(rows + 8 * s + 4 * h);
+                xb[4 * s + 0] = xcol[(int64_t)rr.x * p.ldb];
+                xb[4 * s + 1] = xcol[(int64_t)rr.y * p.ldb];
+                xb[4 * s + 2] = xcol[(int64_t)rr.z * p.ldb];
+                xb[4 * s + 3] = xcol[(int64_t)rr.w * p.ldb];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SU; ++q) {
+            const int u = tid + q * 64 * NW;
+            *reinterpret_cast<f32x4*>(As + (u / (KC / 4)) * LDA + 4 * (u % (KC / 4))) = sv[q];
+        }
+        __syncthreads();
+        if (wave_on) {
+#pragma unroll
+            for (int lt = 0; lt < LT; ++lt) {
+                if (m0 + 32 * lt < p.M) {            // uniform
+                    const float* arow = As + (32 * lt + i) * LDA + 4 * h;
+#pragma unroll
+                    for (int s = 0; s < KC / 8; ++s) {
+                        const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + 8 * s);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], xb[4 * s + t], acc[lt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                             // everybody is done with this chunk's LDS
+    }
+    if (!wave_on) return;
+
+    if (EPI != OV_EPI_ADAMW) {
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ov_buf_store(acc[lt][r], row_rsrc(p.C, m0 + 32 * lt, r), lane_off, 0, 0);
+        return;
+    }
+    float w[2][16], mm[2][16], vv[2][16];
+    auto request = [&](int buf, int lt) {
+        const int mb = m0 + 32 * lt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            w[buf][r] = ov_buf_load(row_rsrc(p.C, mb, r), lane_off, 0, 0);
+            mm[buf][r] = ov_buf_load(row_rsrc(p.Pm, mb, r), lane_off, 0, 0);
+            vv[buf][r] = ov_buf_load(row_rsrc(p.Pv, mb, r), lane_off, 0, 0);
+        }
+    };
+    request(0, 0);
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) {
+        const int buf = lt & 1;
+        const int mb = m0 + 32 * lt;
+        if (mb < p.M) {                              // uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ov_adamw_fast(w[buf][r], mm[buf][r], vv[buf][r], acc[lt][r], p.adam, false);
+            __builtin_amdgcn_sched_barrier(0);
+            if (lt + 1 < LT && mb + 32 < p.M) request(buf ^ 1, lt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ov_buf_store(w[buf][r], row_rsrc(p.C, mb, r), lane_off, 0, 0);
+                ov_buf_store(mm[buf][r], row_rsrc(p.Pm, mb, r), lane_off, 0, 0);
+                ov_buf_store(vv[buf][r], row_rsrc(p.Pv, mb, r), lane_off, 0, 0);
+            }
+        }
+    }
 }
 
 #endif

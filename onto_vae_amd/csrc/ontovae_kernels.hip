@@ -1808,15 +1808,15 @@ static inline bool ov_al16(const void* p) { return (reinterpret_cast<uintptr_t>(
 template <int EPI>
 static int ov_launch_dw0(const OvGemm& g, hipStream_t st) {
     constexpr int NW = 8;
-    if (g.K > 128 || (g.lda & 3) || !ov_al16(g.A) || (int64_t)g.M * g.ldc * 4 >= (int64_t)1 << 31) {
-        ontovae_set_error("dw0: needs K <= 128, 16-B aligned dh rows and a parameter below 2 GiB");
+    if ((g.lda & 3) || (g.a_blm & 3) || (g.a_rstride & 3) || !ov_al16(g.A) || (int64_t)g.M * g.ldc * 4 >= (int64_t)1 << 31) {
+        ontovae_set_error("dw0: needs 16-B aligned dh rows and a parameter below 2 GiB");
         return ONTOVAE_EINVAL;
     }
     const int njobs = (g.M + 127) / 128;
     const int gxn = (g.N + 32 * NW - 1) / (32 * NW);
     const int blocks = (gxn + 7) / 8 * 8 * njobs;
     const size_t lds = (size_t)128 * 132 * sizeof(float) + 128 * sizeof(int32_t);
-    auto kern = ov_dw0_kernel<NW, EPI>;
+    auto kern = (g.K <= 128 && g.a_blm == 0) ? ov_dw0_kernel<NW, EPI> : ov_dw0_multi_kernel<NW, EPI>;
     OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, g, njobs);
     OV_LAUNCH_CHECK();
@@ -2458,7 +2458,7 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     g.adam = ov_adam_from(opt);
     g.dbg = (c->flags >> 16) & 7;
     OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
-    const bool resident = s.B <= 128 && (s.ldb % 4 == 0) && ov_al16(g.A) && (int64_t)d.L * d.G * 4 < ((int64_t)1 << 31) &&
+    const bool resident = (s.ldb % 4 == 0) && ov_al16(g.A) && (int64_t)d.L * d.G * 4 < ((int64_t)1 << 31) &&
                           !((c->flags >> 22) & 1);
     if (apply) {
         g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
