@@ -151,7 +151,7 @@ def main():
         i = it[0]
         idx = perm[(i % nb) * Bg:(i % nb + 1) * Bg]
         if world > 1:
-            dp_train_step(model, X, idx, None, kc, opt, loss[i % loss.shape[0]])
+            dp_train_step(model, X, idx, None, kc, opt, loss[i % loss.shape[0]], reduce_loss=False)
         else:
             e.train_step(X, idx, None, kc, opt.next_hyper(), loss[i % loss.shape[0]])
         it[0] += 1

@@ -248,6 +248,31 @@ int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, const float* 
 /* torch.optim.AdamW.step over the flat buffers (vae_model.py:172) + clamp(0) of the packed
  * decoder weights (vae_model.py:175-176), reading gradients from ctx->Gr. */
 int ontovae_adamw_apply(const ontovae_ctx_t* ctx, const ontovae_adamw_t* opt, void* stream);
+/* The same over the float range [begin, end) of the layout only. */
+int ontovae_adamw_apply_range(const ontovae_ctx_t* ctx, const ontovae_adamw_t* opt, int64_t begin, int64_t end,
+                              void* stream);
+
+/* Data-parallel step WITHOUT an all-reduce of the first layer's weight gradient (28.8 MB at GO-BP scale, the
+ * bulk of the gradient): dW0 = dh x is bilinear in two small things every rank can have, the BN-backward output
+ * dh [L, B_global] (1.5 MB at 8 x 128 rows) and the rows of the replicated, HBM-resident dataset.  So the ranks
+ * all-gather dh and each forms dW0 of the GLOBAL batch (+ AdamW, identical on every rank) itself.  No counterpart
+ * in the reference (single device); same contract as ontovae_train_step_dp.  After phases 0 and 1 of
+ * ontovae_train_step_dp:
+ *   ontovae_dp_bn_bwd: BN backward with the all-reduced bn_bwd_stats.  Gradients of gamma and beta (GLOBAL sums)
+ *     and of b0 (LOCAL sum) go to ctx->Gr; send = this rank's block for the all-gather, floats:
+ *     [L][blm] dh (columns >= B zero) then [L] the local b0 gradient; blm % 4 == 0, blm >= B.
+ *   caller: all-gather of the blocks (rank stride `rstride` floats, % 4 == 0).
+ *   ontovae_dw0_global: dW0 over the gathered blocks: column k = r * blm + j of rank block r is column
+ *     c = colmap ? colmap[k] : k of the global batch, i.e. dataset row xidx ? xidx[c] : c (padding slots: any valid
+ *     column, their dh is 0); AdamW on W0 if apply_update != 0, else the gradient to ctx->Gr.  Also sums the
+ *     blocks' b0 parts into ctx->Gr (when Gr is there).
+ * ontovae_train_step_dp phase 16 + R: phase 1 with bn_stats = the R ranks' all-gathered blocks [mean | M2 | rows]
+ *   (2 L + 1 floats each) instead of the combined [mean | var]; Chan's combination then happens in the kernel. */
+int ontovae_dp_bn_bwd(const ontovae_ctx_t* ctx, int32_t B, int32_t B_global, const float* bn_bwd_stats,
+                      uint64_t rng_offset, float* send, int32_t blm, void* stream);
+int ontovae_dw0_global(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, const int32_t* colmap,
+                       int32_t n_ranks, int32_t blm, const float* gathered, int64_t rstride, const ontovae_adamw_t* opt,
+                       int32_t apply_update, void* stream);
 
 /* One body of OntoVAE.val_round (onto_vae/vae_model.py:204-209): eval-mode forward + vae_loss. */
 int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B,

@@ -53,6 +53,8 @@ struct OvGemm {
     // A[r * a_rstride + m * lda + j]; a_blm == 0: plain A[m * lda + k]
     int a_blm;
     int64_t a_rstride;
+    const int32_t* colmap;     // optional: gathered column k is column colmap[k] of the global batch (row = bgather[colmap[k]])
+    float* b0sum;              // optional: [M] <- sum over the rank blocks of their trailing [M] floats (local b0 gradients)
 };
 
 template <bool FULL, bool VEC>
@@ -794,6 +796,14 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_multi_kernel(const OvGemm p, i
     };
     const int blm = p.a_blm > 0 ? p.a_blm : 0x40000000;
     const float* xcol = p.B + min(n0 + i, p.N - 1);
+    if (p.b0sum && blockIdx.x == 0 && p.a_blm > 0) {
+        const int nr = p.K / p.a_blm;
+        for (int l = tid; l < p.M; l += 64 * NW) {
+            float sum = 0.f;
+            for (int r = 0; r < nr; ++r) sum += p.A[(int64_t)r * p.a_rstride + (int64_t)p.M * p.a_blm + l];
+            p.b0sum[l] = sum;
+        }
+    }
 
     f32x16 acc[LT];
 #pragma unroll
@@ -824,7 +834,8 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_multi_kernel(const OvGemm p, i
             sv[q] = v;
         }
         for (int t = tid; t < KC; t += 64 * NW) {
-            const int tt = min(kc + t, p.K - 1);
+            int tt = min(kc + t, p.K - 1);
+            if (p.colmap) tt = p.colmap[tt];
             rows[t] = p.bgather ? p.bgather[tt] : tt;
         }
         __syncthreads();

@@ -168,6 +168,7 @@ extern "C" int64_t ontovae_workspace_bytes(const ontovae_dims_t* dims, int32_t m
 // a = relu(dropout(gamma * xhat + beta))                (modules.py:47-49: BN, Dropout, ReLU)
 // mode: 0 eval (running stats), 1 train fused, 2 DP phase 0 (h + local mean/M2 only),
 //       3 DP phase 1 (normalise with the supplied global mean/var; h already in xhat)
+//       5 DP phase 1 with the ranks' all-gathered partial statistics, combined here
 __global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict__ slab, int S, int64_t slab_stride,
                                                        const float* __restrict__ b0, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ rmean,
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict_
     float* xr = xhat + (int64_t)l * ldb;
     float* ar = a + (int64_t)l * ldb;
     float mean, var;
-    if (mode != 3) {
+    if (mode != 3 && mode != 5) {
         const float bias = b0[l];
         float s = 0.f;
         for (int c0 = 0; c0 < ldb; c0 += 256) {
@@ -240,12 +241,29 @@ __global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict_
             }
             var = q / (float)B;
         }
+    } else if (mode == 5) {
+        // the ranks' all-gathered (mean, M2, rows) blocks, S of them with stride slab_stride: Chan's combination
+        if (wave != 0) return;
+        float n = 0.f, m = 0.f;
+        for (int r = 0; r < S; ++r) {
+            const float nr = stats[r * slab_stride + 2 * L];
+            n += nr;
+            m += nr * stats[r * slab_stride + l];
+        }
+        mean = m / n;
+        float m2 = 0.f;
+        for (int r = 0; r < S; ++r) {
+            const float nr = stats[r * slab_stride + 2 * L];
+            const float dm = stats[r * slab_stride + l] - mean;
+            m2 += stats[r * slab_stride + L + l] + nr * dm * dm;
+        }
+        var = m2 / n;
     } else {
         if (wave != 0) return;
         mean = stats[l];
         var = stats[L + l];
     }
-    if (mode == 1 || mode == 3) {
+    if (mode == 1 || mode == 3 || mode == 5) {
         if (lane == 0) {
             const float mom = 0.1f;
             const float nb = (float)Bglobal;
@@ -287,6 +305,7 @@ struct OvBnBwdArgs {
     float* dh; float* bwd_local; float* bwd_stats;
     int L, B, Bglobal, ldb, mode, apply_update; OvAdam adam; float drop; uint64_t seed, rng_off;
     int daS; int64_t dastride;
+    float* send; int blm;          // mode 4: also [L][blm] dh + [L] local b0 gradient for the all-gather
 };
 // block: this workgroup's number inside the BatchNorm part, 4 features per workgroup
 __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int block) {
@@ -305,7 +324,7 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
     const int lane = ov_lane();
     const int64_t ro = (int64_t)l * ldb;
     float sdy = 0.f, sdyx = 0.f;
-    if (mode != 3) {
+    if (mode < 3) {
         for (int b = lane; b < ldb; b += 64) {
             float dy = 0.f;
             if (b < B) {
@@ -328,9 +347,10 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
         }
     }
     float gdy = sdy, gdyx = sdyx;          // global sums
-    if (mode == 3) {
+    if (mode >= 3) {
         gdy = bwd_stats[l]; gdyx = bwd_stats[L + l];
         sdy = bwd_local[l]; sdyx = bwd_local[L + l];
+        if (mode == 4) { sdy = gdy; sdyx = gdyx; }      // gradients of gamma / beta: the global sums, on every rank
     }
     const float g = P_gamma[l];
     const float is = invstd[l];
@@ -344,8 +364,10 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
             sdh += v;
         }
         dh[ro + b] = v;
+        if (mode == 4 && b < q.blm) q.send[(int64_t)l * q.blm + b] = v;
     }
     sdh = ov_wave_sum(sdh);
+    if (mode == 4 && lane == 0) q.send[(int64_t)L * q.blm + l] = sdh;
     if (lane == 0) {
         if (apply_update) {
             float w, m, v;
@@ -1909,11 +1931,12 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     return ov_launch_gemm<3, 4, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
 }
 
+// mode 5: S = number of rank blocks in `stats`, each 2 L + 1 floats
 static int ov_bn_fwd(OvStep& s, int S, int mode, int Bglobal, float* stats, uint64_t rng_off) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     OvProfScope prof(ONTOVAE_PHASE_BN_FWD, s.st);
-    hipLaunchKernelGGL(ov_bn_fwd_kernel, dim3(d.L), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb,
+    hipLaunchKernelGGL(ov_bn_fwd_kernel, dim3(d.L), dim3(256), 0, s.st, s.ws.slab, S, mode == 5 ? (int64_t)(2 * d.L + 1) : (int64_t)d.L * s.ldb,
                        c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, c->bn_nbt,
                        s.ws.xhat, s.ws.a, s.ws.bn_mean, s.ws.bn_invstd, stats, d.L, s.B, Bglobal, s.ldb, mode, c->drop, c->seed,
                        rng_off);
@@ -2419,7 +2442,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                          c->M ? c->M + lay.b0 : nullptr, c->V ? c->V + lay.gamma : nullptr, c->V ? c->V + lay.beta : nullptr,
                          c->V ? c->V + lay.b0 : nullptr, Gr ? Gr + lay.gamma : nullptr, Gr ? Gr + lay.beta : nullptr,
                          Gr ? Gr + lay.b0 : nullptr, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, s.B, Bglobal, s.ldb, bn_mode,
-                         apply, adam, c->drop, c->seed, rng_off, da_S, (int64_t)d.L * s.ldb};
+                         apply, adam, c->drop, c->seed, rng_off, da_S, (int64_t)d.L * s.ldb, nullptr, 0};
     const int bn_blocks = (d.L + 3) / 4;
     if (!s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS)) {
         OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
@@ -2517,8 +2540,11 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
         int S = 1;
         if ((rc = ov_enc_gemm(s, &S))) return rc;
         return ov_bn_fwd(s, S, 2, B_global, bn_stats, rng_offset);
-    } else if (phase == 1) {
-        if ((rc = ov_bn_fwd(s, 1, 3, B_global, bn_stats, rng_offset))) return rc;
+    } else if (phase == 1 || phase >= 16) {
+        // phase 16 + R: as phase 1, but bn_stats holds the R ranks' all-gathered blocks [mean | M2 | rows] (2 L + 1 floats
+        // each) and the combination to the global mean / variance happens inside the BatchNorm kernel
+        if (phase >= 16) { if ((rc = ov_bn_fwd(s, phase - 16, 5, B_global, bn_stats, rng_offset))) return rc; }
+        else if ((rc = ov_bn_fwd(s, 1, 3, B_global, bn_stats, rng_offset))) return rc;
         s.side = ov_side_get(ctx);
         if ((rc = ov_train_tail_a(s, eps, rng_offset, kl_coeff, nullptr, 0, loss_out, 2, bn_bwd_stats, B_global, false))) return rc;
         return ov_side_join(s);
@@ -2529,7 +2555,7 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
         const OvBnBwdArgs bn{s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd, ctx->P + lay.gamma, ctx->P + lay.beta, ctx->P + lay.b0,
                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->Gr + lay.gamma, ctx->Gr + lay.beta,
                              ctx->Gr + lay.b0, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, B, B_global, s.ldb, 3, 0, adam,
-                             ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0};
+                             ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0, nullptr, 0};
         hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, bn);
         OV_LAUNCH_CHECK();
         return ov_dw0(s, nullptr, 0);
@@ -2547,6 +2573,72 @@ extern "C" int ontovae_adamw_apply(const ontovae_ctx_t* ctx, const ontovae_adamw
                        ctx->Gr, n, lay.dec_vals, lay.dec_vals + ctx->dims.nnz, ov_adam_from(opt));
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_adamw_apply_range(const ontovae_ctx_t* ctx, const ontovae_adamw_t* opt, int64_t begin, int64_t end,
+                                         void* stream) {
+    if (!ctx || !opt || !ctx->P || !ctx->M || !ctx->V || !ctx->Gr) { ontovae_set_error("adamw_apply_range: a required pointer is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_layout_t& lay = ctx->lay;
+    if (begin < 0 || end > lay.total || begin > end) { ontovae_set_error("adamw_apply_range: bad range"); return ONTOVAE_EINVAL; }
+    const int64_t n = end - begin;
+    if (n == 0) return ONTOVAE_OK;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    // clamp range relative to the sub-buffer
+    hipLaunchKernelGGL(ov_adamw_flat_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ctx->P + begin,
+                       ctx->M + begin, ctx->V + begin, ctx->Gr + begin, n, lay.dec_vals - begin, lay.dec_vals + ctx->dims.nnz - begin,
+                       ov_adam_from(opt));
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_dp_bn_bwd(const ontovae_ctx_t* ctx, int32_t B, int32_t B_global, const float* bn_bwd_stats,
+                                 uint64_t rng_offset, float* send, int32_t blm, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!bn_bwd_stats || !send || !ctx->Gr) { ontovae_set_error("dp_bn_bwd: a required pointer is NULL"); return ONTOVAE_EINVAL; }
+    if (blm < B || (blm & 3) || B_global < B) { ontovae_set_error("dp_bn_bwd: blm %d must be a multiple of 4 and >= B = %d", blm, B); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, nullptr, nullptr, B, stream, &s);
+    if (blm > s.ldb) { ontovae_set_error("dp_bn_bwd: blm %d exceeds the padded batch %d", blm, s.ldb); return ONTOVAE_EINVAL; }
+    const ontovae_dims_t& d = ctx->dims;
+    const ontovae_layout_t& lay = ctx->lay;
+    OvAdam adam{};
+    const OvBnBwdArgs bn{s.ws.da, s.ws.a, s.ws.xhat, s.ws.bn_invstd, ctx->P + lay.gamma, ctx->P + lay.beta, ctx->P + lay.b0,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->Gr + lay.gamma, ctx->Gr + lay.beta,
+                         ctx->Gr + lay.b0, s.ws.dh, s.ws.bn_bwd_local, const_cast<float*>(bn_bwd_stats), d.L, B, B_global, s.ldb, 4, 0,
+                         adam, ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0, send, blm};
+    OvProfScope prof(ONTOVAE_PHASE_BN_BWD, s.st);
+    hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, bn);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_dw0_global(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, const int32_t* colmap,
+                                  int32_t n_ranks, int32_t blm, const float* gathered, int64_t rstride,
+                                  const ontovae_adamw_t* opt, int32_t apply_update, void* stream) {
+    if (!ctx || !x || (!xidx && !colmap) || !gathered || n_ranks < 1 || blm < 4 || (blm & 3) || (rstride & 3) ||
+        rstride < (int64_t)ctx->dims.L * (blm + 1)) {
+        ontovae_set_error("dw0_global: bad arguments");
+        return ONTOVAE_EINVAL;
+    }
+    if (apply_update && (!opt || !ctx->M || !ctx->V)) { ontovae_set_error("dw0_global: optimizer state missing"); return ONTOVAE_EINVAL; }
+    if (!apply_update && !ctx->Gr) { ontovae_set_error("dw0_global: gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_dims_t& d = ctx->dims;
+    OvGemm g{};
+    g.M = d.L; g.N = d.G; g.K = n_ranks * blm;
+    g.A = gathered; g.lda = blm; g.a_blm = blm; g.a_rstride = rstride;
+    g.B = x; g.ldb = d.G; g.bgather = xidx; g.colmap = colmap;
+    g.ldc = d.G;
+    g.adam = ov_adam_from(opt);
+    g.b0sum = ctx->Gr ? ctx->Gr + ctx->lay.b0 : nullptr;       // gradient of b0: sum of the ranks' local sums
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    OvProfScope prof(ONTOVAE_PHASE_DW0, st);
+    if (apply_update) {
+        g.C = ctx->P + ctx->lay.W0; g.Pm = ctx->M + ctx->lay.W0; g.Pv = ctx->V + ctx->lay.W0;
+        return ov_launch_dw0<OV_EPI_ADAMW>(g, st);
+    }
+    g.C = ctx->Gr + ctx->lay.W0;
+    return ov_launch_dw0<OV_EPI_STORE>(g, st);
 }
 
 // =================================================================================================

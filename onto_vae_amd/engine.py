@@ -288,6 +288,30 @@ class Engine:
         ctx = self.ctx(max(self.max_batch, 1))
         _lib.check(_lib.lib().ontovae_adamw_apply(C.byref(ctx), C.byref(adam), self.stream()), "adamw_apply")
 
+    def adamw_apply_range(self, adam, begin, end):
+        self.ensure_opt_state()
+        self.ensure_grad_buffer()
+        ctx = self.ctx(max(self.max_batch, 1))
+        _lib.check(_lib.lib().ontovae_adamw_apply_range(C.byref(ctx), C.byref(adam), int(begin), int(end), self.stream()),
+                   "adamw_apply_range")
+
+    def dp_bn_bwd(self, B, B_global, bn_bwd_stats, offset, send, blm):
+        self.ensure_grad_buffer()
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_dp_bn_bwd(C.byref(ctx), int(B), int(B_global), _ptr(bn_bwd_stats), offset, _ptr(send),
+                                                int(blm), self.stream()), "dp_bn_bwd")
+
+    def dw0_global(self, x, xidx, colmap, n_ranks, blm, gathered, rstride, adam):
+        """dW0 of the global batch from the all-gathered dh blocks (+ the b0 gradient: sum of the blocks' b0 parts);
+        adam=None stores the gradient in Gr."""
+        self.ensure_grad_buffer()
+        if adam is not None:
+            self.ensure_opt_state()
+        ctx = self.ctx(max(self.max_batch, 1))
+        _lib.check(_lib.lib().ontovae_dw0_global(C.byref(ctx), _ptr(x), _ptr(xidx), _ptr(colmap), int(n_ranks), int(blm), _ptr(gathered),
+                                                 int(rstride), C.byref(adam) if adam is not None else None,
+                                                 1 if adam is not None else 0, self.stream()), "dw0_global")
+
     def eval_step(self, x, xidx, eps, kl_coeff, loss_out):
         x, xidx, B = self._x(x, xidx)
         eps = self._eps(eps, B)

@@ -11,6 +11,8 @@ row 12); the contract is that an R-rank step equals the single-device step on th
 
 No collective is on the inference path: samples are independent, ranks take disjoint slices.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -38,7 +40,97 @@ def grad_buckets(layout):
     return (0, int(layout.Wh)), (int(layout.Wh), int(layout.total))
 
 
-def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None):
+class _DpState:
+    """Per (engine, global batch, world, rank) buffers and index maps of the data-parallel step, built once."""
+
+    def __init__(self, e, B, world, rank):
+        L, dev = e.plan.L, e.device
+        self.start, self.size = shard_bounds(B, world, rank)
+        if self.size < 1:
+            raise ValueError(f"global batch {B} leaves rank {rank} of {world} without rows")
+        sizes = [shard_bounds(B, world, r)[1] for r in range(world)]
+        starts = [shard_bounds(B, world, r)[0] for r in range(world)]
+        self.stats_send = torch.zeros(2 * L + 1, device=dev)          # [mean | M2 | rows of this rank]
+        self.stats_send[2 * L] = float(self.size)
+        self.stats = self.stats_send[:2 * L].view(2, L)
+        self.stats_all = torch.zeros(world * (2 * L + 1), device=dev)      # flat: gloo's all_gather_into_tensor wants 1-D
+        self.counts = torch.tensor([float(n) for n in sizes], device=dev)
+        self.gstats = torch.zeros(2, L, device=dev)
+        self.bstats = torch.zeros(2, L, device=dev)
+        self.lloc = torch.zeros(3, device=dev)
+        # all-gathered dh: per rank [L][blm] + [L] (local b0 gradient), stride padded to 4 floats
+        self.blm = (max(sizes) + 3) // 4 * 4
+        self.rstride = (L * self.blm + L + 3) // 4 * 4
+        self.send = torch.zeros(self.rstride, device=dev)
+        self.gathered = torch.zeros(world * self.rstride, device=dev)
+        # position k = r * blm + j of the gathered columns -> position in the global batch (padding: the rank's first row)
+        m = []
+        for r in range(world):
+            m += [starts[r] + j if j < sizes[r] else starts[r] for j in range(self.blm)]
+        self.colmap = torch.tensor(m, dtype=torch.int64, device=dev)
+        self.colmap32 = self.colmap.to(torch.int32)
+
+
+def _dp_state(e, B, world, rank):
+    cache = getattr(e, "_dp_cache", None)
+    if cache is None:
+        cache = e._dp_cache = {}
+    key = (int(B), int(world), int(rank))
+    if key not in cache:
+        cache[key] = _DpState(e, B, world, rank)
+    return cache[key]
+
+
+def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, reduce_loss=True):
+    """One synchronous data-parallel step.  `x`/`xidx` address the GLOBAL batch (identical on all ranks); `eps`, if
+    given, is the global [B, L] draw.  Exchanges: SyncBN forward (all-gather of 2L+1 floats), SyncBN backward
+    (all-reduce of 2L floats), gradients of the heads and the decoder (all-reduce, 3 MB at GO-BP scale, overlapped
+    with the BatchNorm backward and dW0), and dh [L, B_local] (all-gather): dW0 = dh x of the GLOBAL batch is then
+    formed, and applied, by every rank itself (ontovae_dw0_global), so the 28.8 MB gradient of the first layer never
+    crosses the links.  ONTOVAE_DP_ALLREDUCE=1 selects the plain all-reduce of the whole gradient buffer instead.
+    reduce_loss=False leaves this rank's partial sums in loss_out (the caller all-reduces a whole epoch at once)."""
+    if os.environ.get("ONTOVAE_DP_ALLREDUCE", "0") == "1":
+        return dp_train_step_allreduce(model, x, xidx, eps, kl_coeff, opt, loss_out, group, reduce_loss)
+    e = model._engine
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = x.shape[0] if xidx is None else xidx.shape[0]
+    st = _dp_state(e, B, world, rank)
+    start, size, L = st.start, st.size, e.plan.L
+    if xidx is None:
+        xl, il = x[start:start + size], None
+    else:
+        if xidx.dtype != torch.int32 or xidx.device != e.device:
+            xidx = xidx.to(device=e.device, dtype=torch.int32)
+        xl, il = x, xidx[start:start + size]
+    el = None if eps is None else torch.as_tensor(eps)[start:start + size]
+    off = e.next_offset() * world + rank          # distinct Philox offsets per rank
+    lay = e.plan.layout
+
+    lbuf = loss_out if not reduce_loss else st.lloc        # phase 1 writes {rec, kl, rec + kl_coeff kl} of this rank's rows
+    e.train_step_dp(0, xl, il, B, el, kl_coeff, st.stats, st.bstats, lbuf, off)
+    dist.all_gather_into_tensor(st.stats_all, st.stats_send, group=group)
+
+    e.train_step_dp(16 + world, xl, il, B, el, kl_coeff, st.stats_all, st.bstats, lbuf, off)
+    dist.all_reduce(st.bstats, group=group)
+
+    e.dp_bn_bwd(size, B, st.bstats, off, st.send, st.blm)
+    dist.all_gather_into_tensor(st.gathered, st.send, group=group)
+    # issued after the all-gather (collectives of one communicator run in order, and dW0 waits for the gather only);
+    # it then runs under the dW0 kernel
+    h_early = dist.all_reduce(e.Gr[int(lay.Wh):int(lay.total)], group=group, async_op=True)
+    hyper = opt.next_hyper()
+    if xidx is None:
+        e.dw0_global(e._x(x, None)[0], None, st.colmap32, world, st.blm, st.gathered, st.rstride, hyper)
+    else:
+        e.dw0_global(x, xidx, st.colmap32, world, st.blm, st.gathered, st.rstride, hyper)
+    h_early.wait()
+    e.adamw_apply_range(hyper, int(lay.b0), int(lay.total))
+    if reduce_loss:
+        dist.all_reduce(st.lloc, group=group)
+        loss_out.copy_(st.lloc)
+
+
+def dp_train_step_allreduce(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, reduce_loss=True):
     """One synchronous data-parallel step.  `x`/`xidx` address the GLOBAL batch (identical on all
     ranks); `eps`, if given, is the global [B, L] draw."""
     e = model._engine
@@ -72,7 +164,8 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None):
 
     e.train_step_dp(2, xl, il, B, el, kl_coeff, stats, bstats, lloc, off)
     h_late = dist.all_reduce(e.Gr[late[0]:late[1]], group=group, async_op=True)
-    dist.all_reduce(lloc, group=group)
+    if reduce_loss:
+        dist.all_reduce(lloc, group=group)
     h_early.wait()
     h_late.wait()
     e.adamw_apply(opt.next_hyper())

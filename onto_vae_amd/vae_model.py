@@ -202,10 +202,12 @@ class OntoVAE(nn.Module):
             B = x.shape[0] if xidx is None else xidx.shape[0]
             if self._dp_world() > 1:
                 from .parallel import dp_train_step
-                dp_train_step(self, x, xidx, self._eps(B), kl_coeff, opt, losses[n])
+                dp_train_step(self, x, xidx, self._eps(B), kl_coeff, opt, losses[n], reduce_loss=False)
             else:
                 self._engine.train_step(x, xidx, self._eps(B), kl_coeff, opt.next_hyper(), losses[n])
             n += 1
+        if self._dp_world() > 1 and n > 0:
+            torch.distributed.all_reduce(losses[:n])        # the ranks' partial sums of the whole epoch, once
         return self._collect(losses, n, 'train', run) / len(dataloader)
 
     def val_round(self, dataloader, kl_coeff, run=None):

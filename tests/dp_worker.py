@@ -1,0 +1,46 @@
+"""Worker of tests/test_gpu_parity.py::test_dp_two_processes_one_gpu: rank `argv[1]` of `argv[2]` processes that share
+GPU 0 and talk through gloo (NCCL/RCCL refuses two ranks on one device); runs `argv[5]` data-parallel steps on the
+inputs in `argv[4]` and saves its parameters.  The code path is the one bench.py --gpus N takes, collectives included."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    rank, world, port, path, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from onto_vae_amd.synthetic import StubOntobj
+    from onto_vae_amd.vae_model import OntoVAE, FusedAdamW
+    from onto_vae_amd.parallel import dp_train_step
+    z = np.load(path, allow_pickle=False)
+    masks = [z[f"mask{i}"] for i in range(int(z["nmask"]))]
+    onto = StubOntobj(masks, data={"d": np.zeros((2, masks[-1].shape[0]))})
+    torch.manual_seed(0)
+    model = OntoVAE(onto, "d", neuronnum=int(z["nu"]), drop=0.0, z_drop=0.0)
+    model.to("cuda:0")
+    model.load_state_dict({k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith("sd:")})
+    X = torch.as_tensor(z["X"]).cuda()
+    idx = torch.as_tensor(z["idx"]).cuda()
+    eps = torch.as_tensor(z["eps"])
+    B = int(z["B"])
+    opt = FusedAdamW(model, lr=float(z["lr"]))
+    losses = torch.zeros(steps, 3, device="cuda")
+    for s in range(steps):
+        ii = idx[s * B:(s + 1) * B]
+        if int(z["use_idx"]):
+            dp_train_step(model, X, ii, eps[s], 1e-4, opt, losses[s])
+        else:
+            dp_train_step(model, X[ii.long()], None, eps[s], 1e-4, opt, losses[s])
+    torch.cuda.synchronize()
+    np.savez(path + f".rank{rank}.npz", P=model._engine.P.cpu().numpy(), losses=losses.cpu().numpy())
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
