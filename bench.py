@@ -202,7 +202,8 @@ def main():
 
     if rank == 0:
         value = Bg * a.steps / dt
-        cost = phase_cost(dom, d, B, int(e.plan.rowptr[d.C]))
+        # data parallel: every rank forms dW0 of the GLOBAL batch (parallel.py), the other kernels see the local rows
+        cost = phase_cost(dom, d, Bg if dom == "dw0" else B, int(e.plan.rowptr[d.C]))
         roof = None
         if cost is not None:
             nbytes, flops = cost
