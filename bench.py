@@ -104,6 +104,62 @@ def cpu_baseline(masks, B, budget_s=20.0):
                       f"dense numpy oracle (oracle/ontovae_oracle.py) on {use} threads"}
 
 
+def infer_bench(a, model, dev, world, rank):
+    """Inference throughput: every rank streams its own rows (no collective), activities written to a resident
+    [rows, T] output; the kernels are the eval-mode encoder, the term chain and the nu-mean (no gene layer)."""
+    import torch.distributed as dist
+    e = model._engine
+    d = e.plan.dims
+    B = a.batch if a.batch != 128 else 4096
+    rows = max(a.rows // B, 1) * B
+    model.eval()
+    X = synth_X(rows, d.G, dev, seed=1234 + rank)
+    out = torch.empty(rows, e.plan.T, dtype=torch.float32, device=dev)
+    nb = rows // B
+    it = [0]
+
+    def step():
+        i = it[0] % nb
+        e.pass_data(X[i * B:(i + 1) * B], None, None, None, act_out=out[i * B:(i + 1) * B])
+        it[0] += 1
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out[:B]).all()
+    if rank == 0:
+        value = B * world * a.steps / dt
+        # per sample: encoder 2 G L + heads 4 L^2 flops (MFMA-bound, SURVEY.md 8(d)); 4 G bytes in, 4 T out
+        flops = (2.0 * d.G * d.L + 4.0 * d.L * d.L) * B
+        t_mfma = flops / (PEAK_F32_MFMA_TF * 1e12)
+        sec = dt / a.steps
+        print(json.dumps({
+            "metric": "inference samples/sec (GO-BP OntoVAE get_pathway_activities)", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[3]: GOBP-syn get_pathway_activities ('act' output, [rows, 3000] fp32), "
+                                   f"batches of {B} rows from {rows} HBM-resident rows per GPU", "batch_per_gpu": B,
+                       "dataset_rows": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                         "frac": t_mfma / sec, "traffic": None, "kernel": "whole step (encoder GEMM dominates)",
+                         "algorithmic_flops": flops}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +169,9 @@ def main():
     ap.add_argument("--rows", type=int, default=65536, help="synthetic dataset rows resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-phase times to stderr")
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="infer: BASELINE.json configs[3], get_pathway_activities-equivalent (ontovae_pass_data, 'act' output) over "
+                         "the HBM-resident rows in batches of --batch (default 4096 there); a step is one batch")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,6 +195,8 @@ def main():
     model, masks = build_model(dev)
     e = model._engine
     d = e.plan.dims
+    if a.mode == "infer":
+        return infer_bench(a, model, dev, world, rank)
     B = a.batch
     Bg = B * world
     X = synth_X(a.rows, d.G, dev)

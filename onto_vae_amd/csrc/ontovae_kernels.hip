@@ -1715,6 +1715,33 @@ __global__ __launch_bounds__(256) void ov_act_out_kernel(const float* __restrict
     }
 }
 
+// The same for a range of levels in one launch: output column c belongs to the level lv with tstart[lv] <= c < tstart[lv + 1]
+struct OvActLevels { int n; int tstart[OV_MAX_LEVELS + 1]; int node0[OV_MAX_LEVELS]; };
+__global__ __launch_bounds__(256) void ov_act_out_levels_kernel(const float* __restrict__ act, const OvActLevels lv, int c_begin,
+                                                               int c_end, int nu, int B, int ldb, float* __restrict__ out,
+                                                               int64_t ld_out) {
+    __shared__ float tile[32][33];
+    const int j0 = c_begin + blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int c = j0 + jj, b = b0 + tx;
+        float s = 0.f;
+        if (c < c_end && b < B) {
+            int l = 0;
+            while (l + 1 < lv.n && c >= lv.tstart[l + 1]) ++l;
+            const int row = lv.node0[l] + (c - lv.tstart[l]) * nu;
+            for (int a = 0; a < nu; ++a) s += act[(int64_t)(row + a) * ldb + b];
+            s = s / (float)nu;
+        }
+        tile[jj][tx] = s;
+    }
+    __syncthreads();
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int b = b0 + jj, c = j0 + tx;
+        if (c < c_end && b < B) out[(int64_t)b * ld_out + c] = tile[tx][jj];
+    }
+}
+
 __global__ void ov_compose_order_kernel(const int32_t* __restrict__ in, const int64_t* __restrict__ perm,
                                         int32_t* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2268,6 +2295,23 @@ extern "C" int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const
 
 static int ov_act_out(OvStep& s, int lvl_from, int lvl_to, float* act_out, int64_t act_ld) {
     const ontovae_dims_t& d = s.c->dims;
+    if (d.K <= OV_MAX_LEVELS) {          // one launch for the whole range of levels
+        OvActLevels lv;
+        lv.n = d.K;
+        int t0 = 0;
+        for (int lvl = 0; lvl < d.K; ++lvl) {
+            lv.tstart[lvl] = t0;
+            lv.node0[lvl] = s.c->level_begin[lvl];
+            t0 += (s.c->level_end[lvl] - s.c->level_begin[lvl]) / d.nu;
+        }
+        lv.tstart[d.K] = t0;
+        const int c0 = lv.tstart[std::max(lvl_from, 0)], c1 = lv.tstart[std::min(lvl_to, (int)d.K)];
+        if (c1 <= c0) return ONTOVAE_OK;
+        dim3 grid((c1 - c0 + 31) / 32, (s.B + 31) / 32);
+        hipLaunchKernelGGL(ov_act_out_levels_kernel, grid, dim3(256), 0, s.st, s.ws.act, lv, c0, c1, d.nu, s.B, s.ldb, act_out, act_ld);
+        OV_LAUNCH_CHECK();
+        return ONTOVAE_OK;
+    }
     int t0 = 0;
     for (int lvl = 0; lvl < d.K; ++lvl) {
         const int n0 = s.c->level_begin[lvl];
