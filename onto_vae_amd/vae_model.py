@@ -88,7 +88,10 @@ class OntoVAE(nn.Module):
         self.genes = ontobj.genes[key]
         self.in_features = len(self.genes)
         masks = ontobj.masks[key]['decoder']
-        self.layer_dims_dec = np.array([masks[0].shape[1]] + [m.shape[0] for m in masks])
+        from .mask_builder import PackedMasks
+        packed = isinstance(masks, PackedMasks)            # onto_vae_amd.mask_builder.create_masks: links, no dense masks
+        shapes = masks.shapes if packed else [m.shape for m in masks]
+        self.layer_dims_dec = np.array([shapes[0][1]] + [sh[0] for sh in shapes])
         self.latent_dim = self.layer_dims_dec[0] * neuronnum
         self.layer_dims_enc = [self.latent_dim]
         self.neuronnum = neuronnum
@@ -97,7 +100,7 @@ class OntoVAE(nn.Module):
         self.device = 'cuda' if torch.cuda.is_available() else 'cpu'
         self._mask_src = masks
 
-        plan = MaskPlan(masks, neuronnum)
+        plan = MaskPlan(neuronnum=neuronnum, links=masks.links, shapes=masks.shapes) if packed else MaskPlan(masks, neuronnum)
         if plan.G != self.in_features:
             raise ValueError(f"the gene mask has {plan.G} rows but ontobj.genes lists {self.in_features} genes")
         object.__setattr__(self, "_engine", Engine(plan, self.device, drop, z_drop))
