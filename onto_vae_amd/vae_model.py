@@ -229,8 +229,12 @@ class OntoVAE(nn.Module):
         import torch.distributed as dist
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
-    def train_model(self, modelpath, lr=1e-4, kl_coeff=1e-4, batch_size=128, epochs=300, run=None):
-        """vae_model.py:215-273: 80/20 split (seed 42), AdamW defaults, best-val checkpointing."""
+    def train_model(self, modelpath, lr=1e-4, kl_coeff=1e-4, batch_size=128, epochs=300, run=None, resume=None):
+        """vae_model.py:215-273: 80/20 split (seed 42), AdamW defaults, best-val checkpointing.
+
+        resume (not in the reference): path of a checkpoint written by this method; training
+        continues after the epoch it holds, with its parameters, optimizer state, batch order and random streams, so
+        that the continued run equals the uninterrupted one (with dropout off or on)."""
         indices = np.random.RandomState(seed=42).permutation(self.X.shape[0])
         X_train_ind = indices[:round(len(indices) * 0.8)]
         X_val_ind = indices[round(len(indices) * 0.8):]
@@ -242,8 +246,21 @@ class OntoVAE(nn.Module):
 
         val_loss_min = float('inf')
         optimizer = FusedAdamW(self, lr=lr)
+        first_epoch = 0
+        if resume is not None:
+            ck = torch.load(resume, map_location='cpu', weights_only=True)
+            if 'resume' not in ck:
+                raise ValueError("checkpoint holds no resume record (it was not written by onto_vae_amd)")
+            self.load_state_dict(ck['model_state_dict'])
+            optimizer.load_state_dict(ck['optimizer_state_dict'])
+            r = ck['resume']
+            trainloader.order = r['train_order'].to(dev)
+            torch.set_rng_state(r['rng_state'])
+            self._engine.rng_offset = int(r['rng_offset'])
+            val_loss_min = float(ck['loss'])
+            first_epoch = int(ck['epoch']) + 1
 
-        for epoch in range(epochs):
+        for epoch in range(first_epoch, epochs):
             print(f"Epoch {epoch+1} of {epochs}")
             train_epoch_loss = self.train_round(trainloader, lr, kl_coeff, optimizer, run)
             val_epoch_loss = self.val_round(valloader, kl_coeff, run)
@@ -260,6 +277,8 @@ class OntoVAE(nn.Module):
                         'model_state_dict': self.state_dict(),
                         'optimizer_state_dict': optimizer.state_dict(),
                         'loss': val_epoch_loss,
+                        'resume': {'train_order': trainloader.order.cpu(), 'rng_state': torch.get_rng_state(),
+                                   'rng_offset': int(self._engine.rng_offset)},
                     }, modelpath)
                 val_loss_min = val_epoch_loss
 

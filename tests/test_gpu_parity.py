@@ -404,6 +404,32 @@ def test_dp_two_processes_one_gpu(tmp_path, use_idx, allreduce):
     assert (diff > 1e-6 + 1e-4 * np.abs(want[mask])).mean() <= 0.01 and diff.max() <= 2 * steps * lr
 
 
+def test_train_model_resume_equals_uninterrupted(tmp_path, capsys):
+    """train_model(resume=...) (the reference cannot resume): 2 epochs + resume to 4 equals 4
+    epochs in one go, bit for bit, with dropout on (parameters, optimizer state, batch order, Philox offsets restored)."""
+    masks, sd = medium()
+    rng = np.random.RandomState(21)
+    X = np.log1p(rng.poisson(0.5, size=(160, 1000))).astype(np.float32)
+
+    def run(path, epochs, resume=None):
+        torch.manual_seed(123)
+        model, _ = make_model(masks, 3, sd, X=X, drop=0.1, z_drop=0.2)
+        model.train_model(str(path), lr=1e-3, kl_coeff=1e-4, batch_size=32, epochs=epochs, resume=resume)
+        return model
+
+    full = run(tmp_path / "full.pt", 4)
+    run(tmp_path / "part.pt", 2)
+    ck = torch.load(str(tmp_path / "part.pt"), weights_only=True)
+    assert ck["epoch"] in (0, 1) and "resume" in ck
+    cont = run(tmp_path / "cont.pt", 4, resume=str(tmp_path / "part.pt"))
+    capsys.readouterr()
+    assert torch.equal(full._engine.P, cont._engine.P)
+    assert torch.equal(full._engine.M, cont._engine.M) and torch.equal(full._engine.V, cont._engine.V)
+    with pytest.raises(ValueError, match="no resume record"):
+        torch.save({"model_state_dict": full.state_dict(), "epoch": 0, "loss": 1.0}, str(tmp_path / "bare.pt"))
+        run(tmp_path / "x.pt", 1, resume=str(tmp_path / "bare.pt"))
+
+
 def test_gobp_syn_full_size_vs_oracle():
     """BASELINE.json configs[1] at full size (G=20000, T=3000, K=12, B=128): two training steps
     against the dense CPU oracle, then the off-mask / non-negativity invariants."""
