@@ -236,6 +236,37 @@ def test_gradients_vs_oracle(B, flags):
     assert np.abs(e.view("b0", G).cpu().numpy()).max() <= 1e-4 * np.abs(g["encoder.encoder.0.1.bias"]).max()
 
 
+@pytest.mark.parametrize("counts,nu", [((400, 900, 1300, 1000), 3), ((3000, 5000, 6000, 4000, 2500), 2)])
+def test_large_panels_two_and_one_columns_per_workgroup(counts, nu):
+    """Panels that do not fit LDS at 4 batch columns per workgroup (C = 10800 -> 2 columns, C = 41000 -> 1 column,
+    e.g. the deeper full-GO ontology of BASELINE.json configs[4]): gradients against the oracle."""
+    from ontovae_oracle import OracleOntoVAE
+    from onto_vae_amd.synthetic import synthetic_masks, random_state_dict
+    G, B = 200, 48
+    masks = synthetic_masks(list(counts), G, 17)
+    sd = random_state_dict(masks, nu, 18)
+    rng = np.random.RandomState(19)
+    x = np.log1p(rng.poisson(0.5, size=(B, G))).astype(np.float32)
+    L = counts[0] * nu
+    eps = rng.standard_normal((B, L)).astype(np.float32)
+    o = OracleOntoVAE(masks, nu)
+    o.load_state_dict(sd)
+    rec, kl, loss, g = o.gradients(x, eps, 1e-4)
+    model, _ = make_model(masks, nu, sd)
+    e = model._engine
+    assert e.plan.C * 16 > 160 * 1024
+    out = torch.zeros(3, device="cuda")
+    e.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), 1e-4, None, out, apply_update=False)
+    np.testing.assert_allclose(out.cpu().numpy(), [rec, kl, loss], rtol=REL)
+    G_ = e.Gr
+    for i in range(e.plan.K):
+        want = g[f"decoder.decoder.{i}.0.weight"] * o.masks[i]
+        got = e.layer_dense(i, G_).cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), i
+    want = g["encoder.mu.0.weight"]
+    assert np.abs(e.view("Wmu", G_).cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+
+
 def test_row_gather_equals_plain_batch():
     """(dataset, row indices) addressing gives the same step as a gathered batch."""
     from onto_vae_amd.vae_model import FusedAdamW
