@@ -64,7 +64,12 @@ static void build_sell(ontovae_plan* p, int dir) {
     int32_t nchunks = 0;
     for (int d : levels) {
         std::vector<std::pair<int32_t, int32_t>> nodes;   // (len, node)
-        for (int32_t n = p->level_begin[d]; n < p->level_end[d]; ++n) nodes.push_back({hi(n) - lo(n), n});
+        for (int32_t n = p->level_begin[d]; n < p->level_end[d]; ++n) {
+            // backward: a node without term children keeps the gene layer's contribution as it is (the chain kernel loads
+            // every panel row first and writes every row back), so it needs no lane
+            if (dir == 1 && hi(n) == lo(n)) continue;
+            nodes.push_back({hi(n) - lo(n), n});
+        }
         std::stable_sort(nodes.begin(), nodes.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
         S.level_first.push_back((int32_t)(S.node.size() / 64));
         size_t i = 0;
