@@ -81,16 +81,37 @@ def _dp_state(e, B, world, rank):
     return cache[key]
 
 
+# all-reduce time of the first layer's gradient (28.8 MB at GO-BP scale) on point-to-point xGMI, microseconds per MB:
+# 2 ranks share one link, 4 ranks three, 8 ranks seven (~64 GB/s per direction each); ring / direct all-reduce moves
+# 2 (R-1)/R of the buffer per rank
+def _allreduce_us(nbytes, world):
+    links = max(world - 1, 1)
+    return 20.0 + 2.0 * (world - 1) / world * nbytes / (links * 64e9) * 1e6
+
+
+def use_gathered_dh(B_global, world, L, G):
+    """Which exchange for the first layer: every rank forming dW0 of the global batch from all-gathered dh costs MFMA
+    time proportional to the global batch (measured: 0.155 us per row at L = 360, G = 20000, i.e. 2.15e-8 us per row
+    and weight); all-reducing the gradient costs the link time above plus the unfused AdamW pass (~35 us per 7.2 M
+    weights).  ONTOVAE_DP_ALLREDUCE=0/1 overrides."""
+    env = os.environ.get("ONTOVAE_DP_ALLREDUCE")
+    if env in ("0", "1"):
+        return env == "0"
+    w = float(L) * float(G)
+    extra_mfma = 2.15e-8 * w * B_global * (1.0 - 1.0 / world)
+    return extra_mfma < _allreduce_us(4.0 * w, world) + 35.0 * w / 7.2e6
+
+
 def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, reduce_loss=True):
     """One synchronous data-parallel step.  `x`/`xidx` address the GLOBAL batch (identical on all ranks); `eps`, if
-    given, is the global [B, L] draw.  Exchanges: SyncBN forward (all-gather of 2L+1 floats), SyncBN backward
-    (all-reduce of 2L floats), gradients of the heads and the decoder (all-reduce, 3 MB at GO-BP scale, overlapped
-    with the BatchNorm backward and dW0), and dh [L, B_local] (all-gather): dW0 = dh x of the GLOBAL batch is then
-    formed, and applied, by every rank itself (ontovae_dw0_global), so the 28.8 MB gradient of the first layer never
-    crosses the links.  ONTOVAE_DP_ALLREDUCE=1 selects the plain all-reduce of the whole gradient buffer instead.
+    given, is the global [B, L] draw.  Exchanges: SyncBN forward (all-gather of 2L+1 floats per rank, combined inside
+    the BatchNorm kernel), SyncBN backward (all-reduce of 2L floats), gradients of the heads and the decoder
+    (all-reduce, 3 MB at GO-BP scale, under the dW0 kernel), and for the first layer either
+      * dh [L, B_local] (all-gather): dW0 = dh x of the GLOBAL batch is then formed, and applied, by every rank itself
+        (ontovae_dw0_global), so the 28.8 MB gradient never crosses the links; or
+      * the all-reduce of that gradient followed by the flat AdamW pass,
+    whichever use_gathered_dh estimates to be shorter (small global batches: the first; large ones: the second).
     reduce_loss=False leaves this rank's partial sums in loss_out (the caller all-reduces a whole epoch at once)."""
-    if os.environ.get("ONTOVAE_DP_ALLREDUCE", "0") == "1":
-        return dp_train_step_allreduce(model, x, xidx, eps, kl_coeff, opt, loss_out, group, reduce_loss)
     e = model._engine
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B = x.shape[0] if xidx is None else xidx.shape[0]
@@ -113,62 +134,27 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
     e.train_step_dp(16 + world, xl, il, B, el, kl_coeff, st.stats_all, st.bstats, lbuf, off)
     dist.all_reduce(st.bstats, group=group)
 
-    e.dp_bn_bwd(size, B, st.bstats, off, st.send, st.blm)
-    dist.all_gather_into_tensor(st.gathered, st.send, group=group)
-    # issued after the all-gather (collectives of one communicator run in order, and dW0 waits for the gather only);
-    # it then runs under the dW0 kernel
-    h_early = dist.all_reduce(e.Gr[int(lay.Wh):int(lay.total)], group=group, async_op=True)
     hyper = opt.next_hyper()
-    if xidx is None:
-        e.dw0_global(e._x(x, None)[0], None, st.colmap32, world, st.blm, st.gathered, st.rstride, hyper)
+    if use_gathered_dh(B, world, L, e.plan.G):
+        e.dp_bn_bwd(size, B, st.bstats, off, st.send, st.blm)
+        dist.all_gather_into_tensor(st.gathered, st.send, group=group)
+        # issued after the all-gather (collectives of one communicator run in order, and dW0 waits for the gather
+        # only); it then runs under the dW0 kernel
+        h_early = dist.all_reduce(e.Gr[int(lay.Wh):int(lay.total)], group=group, async_op=True)
+        if xidx is None:
+            e.dw0_global(e._x(x, None)[0], None, st.colmap32, world, st.blm, st.gathered, st.rstride, hyper)
+        else:
+            e.dw0_global(x, xidx, st.colmap32, world, st.blm, st.gathered, st.rstride, hyper)
+        h_early.wait()
+        e.adamw_apply_range(hyper, int(lay.b0), int(lay.total))
     else:
-        e.dw0_global(x, xidx, st.colmap32, world, st.blm, st.gathered, st.rstride, hyper)
-    h_early.wait()
-    e.adamw_apply_range(hyper, int(lay.b0), int(lay.total))
+        late, early = grad_buckets(lay)
+        h_early = dist.all_reduce(e.Gr[early[0]:early[1]], group=group, async_op=True)     # under the dW0 GEMM
+        e.train_step_dp(2, xl, il, B, el, kl_coeff, st.stats, st.bstats, lbuf, off)
+        h_late = dist.all_reduce(e.Gr[late[0]:late[1]], group=group, async_op=True)
+        h_early.wait()
+        h_late.wait()
+        e.adamw_apply(hyper)
     if reduce_loss:
         dist.all_reduce(st.lloc, group=group)
         loss_out.copy_(st.lloc)
-
-
-def dp_train_step_allreduce(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, reduce_loss=True):
-    """One synchronous data-parallel step.  `x`/`xidx` address the GLOBAL batch (identical on all
-    ranks); `eps`, if given, is the global [B, L] draw."""
-    e = model._engine
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    B = x.shape[0] if xidx is None else xidx.shape[0]
-    start, size = shard_bounds(B, world, rank)
-    if size < 1:
-        raise ValueError(f"global batch {B} leaves rank {rank} of {world} without rows")
-    if xidx is None:
-        xl, il = x[start:start + size], None
-    else:
-        xl, il = x, xidx[start:start + size]
-    el = None if eps is None else torch.as_tensor(eps)[start:start + size]
-    L = e.plan.L
-    dev = e.device
-    stats = torch.zeros(2, L, device=dev)
-    bstats = torch.zeros(2, L, device=dev)
-    lloc = torch.zeros(3, device=dev)
-    off = e.next_offset() * world + rank          # distinct Philox offsets per rank
-
-    e.train_step_dp(0, xl, il, B, el, kl_coeff, stats, bstats, lloc, off)
-    gathered = [torch.empty(2 * L + 1, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, torch.cat([stats.flatten(), torch.tensor([float(size)], device=dev)]), group=group)
-    g = torch.stack(gathered)
-    stats.copy_(combine_bn_stats(g[:, :2 * L].view(world, 2, L), g[:, 2 * L]))
-
-    e.train_step_dp(1, xl, il, B, el, kl_coeff, stats, bstats, lloc, off)
-    dist.all_reduce(bstats, group=group)
-    late, early = grad_buckets(e.plan.layout)
-    h_early = dist.all_reduce(e.Gr[early[0]:early[1]], group=group, async_op=True)
-
-    e.train_step_dp(2, xl, il, B, el, kl_coeff, stats, bstats, lloc, off)
-    h_late = dist.all_reduce(e.Gr[late[0]:late[1]], group=group, async_op=True)
-    if reduce_loss:
-        dist.all_reduce(lloc, group=group)
-    h_early.wait()
-    h_late.wait()
-    e.adamw_apply(opt.next_hyper())
-    loss_out[0] = lloc[0]
-    loss_out[1] = lloc[1]
-    loss_out[2] = lloc[0] + float(kl_coeff) * lloc[1]
