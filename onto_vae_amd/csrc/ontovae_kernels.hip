@@ -1809,6 +1809,26 @@ static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
     return ONTOVAE_OK;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call of several microseconds: remember, per kernel and
+// device, the largest size that was already granted
+static int ov_allow_lds(const void* kern, size_t bytes) {
+    struct Key { const void* k; int dev; size_t bytes; };
+    static thread_local Key cache[64];
+    static thread_local int n = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < n; ++i)
+        if (cache[i].k == kern && cache[i].dev == dev) {
+            if (cache[i].bytes >= bytes) return ONTOVAE_OK;
+            OV_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            cache[i].bytes = bytes;
+            return ONTOVAE_OK;
+        }
+    OV_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (n < 64) cache[n++] = Key{kern, dev, bytes};
+    return ONTOVAE_OK;
+}
+
 template <int MT, int NT, int KW, int UK, bool A_KC, bool B_KC, int EPI>
 static int ov_launch_gemm(const OvGemm& g, int S, bool vec, hipStream_t st) {
     const int bm = KW == 1 ? 64 * MT : 32 * MT, bn = KW == 1 ? 64 * NT : 32 * NT;
@@ -1827,7 +1847,7 @@ static int ov_launch_gemm(const OvGemm& g, int S, bool vec, hipStream_t st) {
     do {                                                                                                          \
         auto kern = ov_gemm_kernel<MT, NT, KW, UK, A_KC, B_KC, V, EPI>;                                            \
         if (lds > 48 * 1024)                                                                                      \
-            OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            { int rc_ = ov_allow_lds(reinterpret_cast<const void*>(kern), lds); if (rc_) return rc_; } \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);                                                    \
     } while (0)
     if (vec) OV_GL(true); else OV_GL(false);
@@ -1845,7 +1865,7 @@ static int ov_launch_gemm_lds(const OvGemm& g, int S, hipStream_t st) {
     if (lds > 160 * 1024) { ontovae_set_error("gemm_lds: %zu bytes of LDS needed", lds); return ONTOVAE_EINVAL; }
     auto kern = ov_gemm_lds_kernel<WM, WN, B_KC, EPI>;
     if (lds > 48 * 1024)
-        OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_ = ov_allow_lds(reinterpret_cast<const void*>(kern), lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
@@ -1866,7 +1886,7 @@ static int ov_launch_dw0(const OvGemm& g, hipStream_t st) {
     const int blocks = (gxn + 7) / 8 * 8 * njobs;
     const size_t lds = (size_t)128 * 132 * sizeof(float) + 128 * sizeof(int32_t);
     auto kern = (g.K <= 128 && g.a_blm == 0) ? ov_dw0_kernel<NW, EPI> : ov_dw0_multi_kernel<NW, EPI>;
-    OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc_ = ov_allow_lds(reinterpret_cast<const void*>(kern), lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, g, njobs);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
@@ -2063,8 +2083,7 @@ static int ov_fused_bt(const ontovae_ctx_t* c) {
 
 template <typename KernelT>
 static int ov_set_lds(KernelT kernel, size_t bytes) {
-    OV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return ONTOVAE_OK;
+    return ov_allow_lds(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 // SELL weight copies <- parameter buffer; called once per pass before the first chain kernel
