@@ -312,6 +312,38 @@ int ontovae_dense_to_vals(const float* dense, int64_t ld, const int32_t* entry_r
                           const int32_t* entry_col, int64_t k0, int64_t k1, float* vals, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Statistics of a perturbation screen, all on device memory.
+ *
+ * Ontobj.wilcox_test (onto_vae/ontobj.py:651-701) runs, per term or gene i,
+ *   scipy.stats.wilcoxon(perturbed[:, i], control[:, i], zero_method='zsplit', alternative=...)  (:673)
+ * and statsmodels' fdrcorrection on the p-values (:676).  ontovae_wilcoxon_zsplit restates the former
+ * (scipy 1.15 _wilcoxon_nd with method='auto', correction=False: exact null distribution for n <= 50
+ * without ties and zeros, all 2^n sign assignments for n <= 13 with them, normal approximation with
+ * tie correction otherwise), ontovae_fdr_bh the latter (Benjamini-Hochberg, 'indep').
+ *
+ * Both matrices are FEATURE-major: column i of the test is perturbed[i * ld .. i * ld + n), float32;
+ * the difference is taken in float32 as numpy does for float32 inputs.  stat / pval: [ncols] float64;
+ * stat = r_plus (ONTOVAE_ALT_TWO_SIDED: min(r_plus, r_minus)); a NaN in a column gives NaN, NaN.
+ * Columns of up to 32768 samples are ranked inside one workgroup's LDS and need no workspace; longer
+ * ones go through `workspace` (ontovae_wilcoxon_workspace_bytes, 256-byte aligned), in groups of
+ * as many columns as it holds.
+ * ontovae_fdr_bh: nsets independent sets of n p-values, pvals / qvals [nsets, n] float64; workspace of
+ * ontovae_fdr_workspace_bytes, 256-byte aligned.  A NaN p-value makes every q of its set NaN.
+ * ontovae_to_feature_major: dst[f * dst_ld + b] = src[b * src_ld + f], b < B, f < F -- moves one
+ * batch of ontovae_pass_data's sample-major output into the columns of a feature-major matrix.
+ * -------------------------------------------------------------------------------------------*/
+enum { ONTOVAE_ALT_GREATER = 0, ONTOVAE_ALT_LESS = 1, ONTOVAE_ALT_TWO_SIDED = 2 };
+int64_t ontovae_wilcoxon_workspace_bytes(int32_t n, int32_t ncols);
+int ontovae_wilcoxon_zsplit(const float* perturbed, const float* control, int64_t ld, int32_t ncols,
+                            int32_t n, int32_t alternative, double* stat, double* pval, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+int64_t ontovae_fdr_workspace_bytes(int32_t n, int32_t nsets);
+int ontovae_fdr_bh(const double* pvals, int32_t n, int32_t nsets, double* qvals, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+int ontovae_to_feature_major(const float* src, int64_t src_ld, int32_t B, int32_t F, float* dst,
+                             int64_t dst_ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-phase timing with HIP events on the launch stream (measurement only; the reference has no
  * counterpart).  ontovae_profile_begin enables the phases in `phase_mask` (bit = phase id) and
  * reserves `capacity` event pairs per phase; every later launch of an enabled phase is bracketed

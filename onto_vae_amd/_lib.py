@@ -102,6 +102,9 @@ def lib():
         "ontovae_gather_rows": [vp, i64, vp, i32, i32, vp, vp],
         "ontovae_vals_to_dense": [vp, vp, vp, i64, i64, vp, i64, vp],
         "ontovae_dense_to_vals": [vp, i64, vp, vp, i64, i64, vp, vp],
+        "ontovae_wilcoxon_zsplit": [vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp],
+        "ontovae_fdr_bh": [vp, i32, i32, vp, vp, i64, vp],
+        "ontovae_to_feature_major": [vp, i64, i32, i32, vp, i64, vp],
         "ontovae_profile_begin": [C.c_uint32, i32],
         "ontovae_profile_read": [i32, c_f32p, i32, c_i32p],
         "ontovae_profile_end": [],
@@ -114,6 +117,9 @@ def lib():
     L.ontovae_plan_destroy.restype = None
     L.ontovae_workspace_bytes.argtypes = [C.POINTER(Dims), i32]
     L.ontovae_workspace_bytes.restype = C.c_int64
+    for name in ("ontovae_wilcoxon_workspace_bytes", "ontovae_fdr_workspace_bytes"):
+        getattr(L, name).argtypes = [i32, i32]
+        getattr(L, name).restype = C.c_int64
     _lib = L
     return L
 
@@ -124,6 +130,8 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
             "ontovae_adamw_apply", "ontovae_adamw_apply_range", "ontovae_dp_bn_bwd", "ontovae_dw0_global", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
             "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals",
+            "ontovae_wilcoxon_workspace_bytes", "ontovae_wilcoxon_zsplit", "ontovae_fdr_workspace_bytes", "ontovae_fdr_bh",
+            "ontovae_to_feature_major",
             "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end"]
 
 PHASES = ["enc_gemm", "bn_fwd", "heads", "reparam", "dec_fwd_terms", "dec_fwd_gene", "dec_bwd", "loss", "dec_wgrad",

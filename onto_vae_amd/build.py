@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libontovae_hip.so")
-SOURCES = ["ontovae_plan.cpp", "ontovae_kernels.hip"]
+SOURCES = ["ontovae_plan.cpp", "ontovae_kernels.hip", "ontovae_stats.hip"]
 HEADERS = ["ontovae_internal.h", "ontovae_device.h", "ontovae_gemm.h", os.path.join("..", "..", "include", "ontovae_hip.h")]
 
 
