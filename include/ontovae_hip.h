@@ -289,6 +289,24 @@ int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const int32_t* x
                       const float* eps1, const float* eps2, uint64_t rng_offset, float* act_out,
                       int64_t act_ld, float* rec_out, int64_t rec_ld, void* stream);
 
+/* OntoVAE.perturbation (onto_vae/vae_model.py:398-456) for screens of many perturbations of one dataset.
+ * The reference overwrites the listed gene columns of the data and runs the whole pass again (:437-440); the
+ * perturbed input differs from the original in those columns only, so its first encoder layer is
+ *   x' W0^T = x W0^T + sum_p (value_p - x[:, gene_p]) W0[:, gene_p]^T.
+ * ontovae_encode_pre stores x W0^T of a batch (no bias) feature-major in hpre[l * ldh + b]; the caller keeps it for
+ * the screen.  ontovae_pass_data_perturbed is ontovae_pass_data on the UNPERTURBED x plus that cache and the lists
+ * pert_gene / pert_val (HOST arrays, n_pert <= ONTOVAE_MAX_PERTURBED_GENES distinct column indices): the encoder GEMM,
+ * three quarters of the time of a pass, is replaced by the rank-1 terms.  Outputs as ontovae_pass_data; they agree with
+ * a pass over the overwritten data to float32 rounding of the first layer (tests: 1e-4 relative). */
+#define ONTOVAE_MAX_PERTURBED_GENES 64
+int ontovae_encode_pre(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, float* hpre,
+                       int64_t ldh, void* stream);
+int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B,
+                                const float* hpre, int64_t ldh, int32_t n_pert, const int32_t* pert_gene,
+                                const float* pert_val, const float* eps1, const float* eps2,
+                                uint64_t rng_offset, float* act_out, int64_t act_ld, float* rec_out,
+                                int64_t rec_ld, void* stream);
+
 /* OntoDecoder.forward alone (onto_vae/modules.py:303-313) on a caller-supplied z [B, L]:
  * the "decoder-only sparse throughput" leg of the inference benchmark. */
 int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z, int32_t B, float* act_out,

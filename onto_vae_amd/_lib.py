@@ -98,6 +98,8 @@ def lib():
         "ontovae_eval_step": [C.POINTER(Ctx), vp, vp, i32, vp, u64, f32, vp, vp],
         "ontovae_pass_data": [C.POINTER(Ctx), vp, vp, i32, vp, vp, u64, vp, i64, vp, i64, vp],
         "ontovae_decoder_forward": [C.POINTER(Ctx), vp, i32, vp, i64, vp, i64, vp],
+        "ontovae_encode_pre": [C.POINTER(Ctx), vp, vp, i32, vp, i64, vp],
+        "ontovae_pass_data_perturbed": [C.POINTER(Ctx), vp, vp, i32, vp, i64, i32, c_i32p, c_f32p, vp, vp, u64, vp, i64, vp, i64, vp],
         "ontovae_compose_order": [vp, vp, vp, i64, vp],
         "ontovae_gather_rows": [vp, i64, vp, i32, i32, vp, vp],
         "ontovae_vals_to_dense": [vp, vp, vp, i64, i64, vp, i64, vp],
@@ -129,6 +131,7 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_plan_entry_coords", "ontovae_plan_csc_split", "ontovae_plan_sell_sizes", "ontovae_plan_sell_export", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
             "ontovae_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
             "ontovae_adamw_apply", "ontovae_adamw_apply_range", "ontovae_dp_bn_bwd", "ontovae_dw0_global", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
+            "ontovae_encode_pre", "ontovae_pass_data_perturbed",
             "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals",
             "ontovae_wilcoxon_workspace_bytes", "ontovae_wilcoxon_zsplit", "ontovae_fdr_workspace_bytes", "ontovae_fdr_bh",
             "ontovae_to_feature_major",

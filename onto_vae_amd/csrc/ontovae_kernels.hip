@@ -2366,6 +2366,98 @@ extern "C" int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const
     return ONTOVAE_OK;
 }
 
+// ---- perturbation screens: the first encoder layer of a perturbed batch from a cached x W0^T ----------------------
+// sum of the encoder GEMM's split-K slabs -> hpre [L][ldh] (no bias)
+__global__ __launch_bounds__(256) void ov_slab_sum_kernel(const float* __restrict__ slab, int S, int64_t stride, int B, int ldb,
+                                                         float* __restrict__ out, int64_t ldh) {
+    const int l = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float h = 0.f;
+    for (int s = 0; s < S; ++s) h += slab[s * stride + (int64_t)l * ldb + b];
+    out[(int64_t)l * ldh + b] = h;
+}
+
+#define OV_PERT_MAX ONTOVAE_MAX_PERTURBED_GENES
+#define OV_PERT_LB 8
+struct OvPert { int n; int32_t gene[OV_PERT_MAX]; float val[OV_PERT_MAX]; };
+// slab[l][b] = hpre[l][b] + sum_p (val_p - x[b, gene_p]) W0[l, gene_p]: x' differs from x in the listed columns only, so
+// x' W0^T is the cached product plus one rank-1 term per perturbed gene
+__global__ __launch_bounds__(256) void ov_pert_slab_kernel(const float* __restrict__ hpre, int64_t ldh, const float* __restrict__ x,
+                                                          const int32_t* __restrict__ xidx, int64_t xld, const float* __restrict__ W0,
+                                                          int G, const OvPert pt, int L, int B, int ldb, float* __restrict__ slab) {
+    const int l0 = blockIdx.y * OV_PERT_LB, b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= ldb) return;
+    float h[OV_PERT_LB];
+#pragma unroll
+    for (int i = 0; i < OV_PERT_LB; ++i) h[i] = (b < B && l0 + i < L) ? hpre[(int64_t)(l0 + i) * ldh + b] : 0.f;
+    if (b < B) {
+        const float* xr = x + (int64_t)(xidx ? xidx[b] : b) * xld;
+        for (int p = 0; p < pt.n; ++p) {
+            const int g = pt.gene[p];
+            const float d = pt.val[p] - xr[g];
+#pragma unroll
+            for (int i = 0; i < OV_PERT_LB; ++i)
+                if (l0 + i < L) h[i] += d * W0[(int64_t)(l0 + i) * G + g];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < OV_PERT_LB; ++i)
+        if (l0 + i < L) slab[(int64_t)(l0 + i) * ldb + b] = h[i];
+}
+
+extern "C" int ontovae_encode_pre(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, float* hpre, int64_t ldh,
+                                  void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!x || !hpre || ldh < B) { ontovae_set_error("encode_pre: x or hpre is NULL, or ldh < B"); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, x, xidx, B, stream, &s);
+    int S = 1;
+    if ((rc = ov_enc_gemm(s, &S))) return rc;
+    const ontovae_dims_t& d = ctx->dims;
+    hipLaunchKernelGGL(ov_slab_sum_kernel, dim3((B + 255) / 256, d.L), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb, B, s.ldb, hpre, ldh);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* hpre,
+                                           int64_t ldh, int32_t n_pert, const int32_t* pert_gene, const float* pert_val,
+                                           const float* eps1, const float* eps2, uint64_t rng_offset, float* act_out, int64_t act_ld,
+                                           float* rec_out, int64_t rec_ld, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    const ontovae_dims_t& d = ctx->dims;
+    if (!x || !hpre || ldh < B) { ontovae_set_error("pass_data_perturbed: x or hpre is NULL, or ldh < B"); return ONTOVAE_EINVAL; }
+    if (n_pert < 0 || n_pert > OV_PERT_MAX || (n_pert && (!pert_gene || !pert_val))) {
+        ontovae_set_error("pass_data_perturbed: n_pert = %d outside [0, %d] or NULL lists", n_pert, OV_PERT_MAX);
+        return ONTOVAE_EINVAL;
+    }
+    if ((act_out && act_ld < d.T) || (rec_out && rec_ld < d.G)) { ontovae_set_error("pass_data_perturbed: output leading dimension too small"); return ONTOVAE_EINVAL; }
+    OvPert pt{};
+    pt.n = n_pert;
+    for (int p = 0; p < n_pert; ++p) {
+        if (pert_gene[p] < 0 || pert_gene[p] >= d.G) { ontovae_set_error("pass_data_perturbed: gene index %d outside [0, %d)", pert_gene[p], d.G); return ONTOVAE_EINVAL; }
+        for (int q = 0; q < p; ++q)
+            if (pert_gene[q] == pert_gene[p]) { ontovae_set_error("pass_data_perturbed: gene index %d listed twice", pert_gene[p]); return ONTOVAE_EINVAL; }
+        pt.gene[p] = pert_gene[p];
+        pt.val[p] = pert_val[p];
+    }
+    OvStep s;
+    ov_make_step(ctx, x, xidx, B, stream, &s);
+    hipLaunchKernelGGL(ov_pert_slab_kernel, dim3((s.ldb + 255) / 256, (d.L + OV_PERT_LB - 1) / OV_PERT_LB), dim3(256), 0, s.st, hpre, ldh, s.x,
+                       s.xidx, s.xld, ctx->P + ctx->lay.W0, d.G, pt, d.L, B, s.ldb, s.ws.slab);
+    OV_LAUNCH_CHECK();
+    if ((rc = ov_bn_fwd(s, 1, 0, s.B, nullptr, rng_offset))) return rc;
+    if ((rc = ov_heads_fwd(s))) return rc;
+    if ((rc = ov_reparam(s, eps1, 0, rng_offset, OV_RNG_EPS, 0, nullptr, true))) return rc;
+    if (act_out && (rc = ov_act_out(s, 0, 1, act_out, act_ld))) return rc;
+    if ((rc = ov_reparam(s, eps2, 0, rng_offset, OV_RNG_EPS2, 0, nullptr, false))) return rc;
+    if ((rc = ov_dec_forward_terms(s, true))) return rc;
+    if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld))) return rc;
+    if (rec_out && (rc = ov_dec_gene<2>(s, rec_out, rec_ld))) return rc;
+    return ONTOVAE_OK;
+}
+
 extern "C" int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z, int32_t B, float* act_out, int64_t act_ld,
                                        float* rec_out, int64_t rec_ld, void* stream) {
     int rc = ov_check_ctx(ctx, B, false);

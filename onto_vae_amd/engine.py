@@ -328,6 +328,30 @@ class Engine:
                                                 _ptr(rec_out), rec_out.stride(0) if rec_out is not None else 0, self.stream()),
                    "pass_data")
 
+    def encode_pre(self, x, xidx, hpre, col0=0):
+        """x W0^T of one batch (no bias) into columns [col0, col0 + B) of the feature-major cache hpre [L, ld]."""
+        x, xidx, B = self._x(x, xidx)
+        if hpre.dtype != torch.float32 or hpre.dim() != 2 or hpre.shape[0] != self.plan.L or hpre.stride(1) != 1 or col0 + B > hpre.shape[1]:
+            raise ValueError(f"hpre must be float32 [{self.plan.L}, >= {col0 + B}]")
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_encode_pre(C.byref(ctx), _ptr(x), _ptr(xidx), B, C.c_void_p(hpre.data_ptr() + 4 * col0),
+                                                 hpre.stride(0), self.stream()), "encode_pre")
+
+    def pass_data_perturbed(self, x, xidx, hpre, col0, genes, values, eps1, eps2, act_out=None, rec_out=None):
+        """pass_data of the batch with columns `genes` of x replaced by `values`, from the cache encode_pre filled."""
+        x, xidx, B = self._x(x, xidx)
+        eps1, eps2 = self._eps(eps1, B), self._eps(eps2, B)
+        genes = np.ascontiguousarray(genes, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        if genes.ndim != 1 or genes.shape != values.shape:
+            raise ValueError("genes and values must be 1-D and of equal length")
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_pass_data_perturbed(
+            C.byref(ctx), _ptr(x), _ptr(xidx), B, C.c_void_p(hpre.data_ptr() + 4 * col0), hpre.stride(0), len(genes),
+            genes.ctypes.data_as(_lib.c_i32p), values.ctypes.data_as(_lib.c_f32p), _ptr(eps1), _ptr(eps2), self.next_offset(),
+            _ptr(act_out), act_out.stride(0) if act_out is not None else 0, _ptr(rec_out),
+            rec_out.stride(0) if rec_out is not None else 0, self.stream()), "pass_data_perturbed")
+
     def decoder_forward(self, z, act_out=None, rec_out=None):
         z = torch.as_tensor(z, dtype=torch.float32, device=self.device).contiguous()
         if z.dim() != 2 or z.shape[1] != self.plan.L:

@@ -50,9 +50,9 @@ def to_feature_major(src, dst, col0=0):
     return dst
 
 
-def wilcoxon_zsplit(perturbed_fm, control_fm, n=None, alternative="greater"):
+def wilcoxon_zsplit(perturbed_fm, control_fm, n=None, alternative="greater", out=None):
     """Paired signed-rank test of every row of two feature-major float32 [C, ld] device matrices over their first n
-    columns (samples).  Returns (stat, pval), float64 [C] on the device."""
+    columns (samples).  Returns (stat, pval), float64 [C] on the device (written into `out` = (stat, pval) if given)."""
     _need_gpu(perturbed_fm, "wilcoxon_zsplit")
     a, b = perturbed_fm, control_fm
     if a.dim() != 2 or a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32 or a.device != b.device:
@@ -65,8 +65,14 @@ def wilcoxon_zsplit(perturbed_fm, control_fm, n=None, alternative="greater"):
     n = a.shape[1] if n is None else int(n)
     if n < 0 or n > a.shape[1]:
         raise ValueError(f"wilcoxon_zsplit: n = {n} outside [0, {a.shape[1]}]")
-    stat = torch.empty(ncols, dtype=torch.float64, device=a.device)
-    pval = torch.empty(ncols, dtype=torch.float64, device=a.device)
+    if out is None:
+        stat = torch.empty(ncols, dtype=torch.float64, device=a.device)
+        pval = torch.empty(ncols, dtype=torch.float64, device=a.device)
+    else:
+        stat, pval = out
+        for t in (stat, pval):
+            if t.dtype != torch.float64 or t.shape != (ncols,) or not t.is_contiguous() or t.device != a.device:
+                raise ValueError(f"wilcoxon_zsplit: out tensors must be contiguous float64 [{ncols}] on {a.device}")
     L = _lib.lib()
     keep, ws, nbytes = _workspace(L.ontovae_wilcoxon_workspace_bytes(n, ncols), a.device)
     _lib.check(L.ontovae_wilcoxon_zsplit(_ptr(a), _ptr(b), a.stride(0) if ncols > 1 else max(a.stride(0), n), ncols, n,

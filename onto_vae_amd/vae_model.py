@@ -115,6 +115,9 @@ class OntoVAE(nn.Module):
         # test hook: callable(B) -> eps [B, L]; None = Philox stream inside the kernels
         self.eps_source = None
         self.inference_batch = 4096
+        # perturbation_screen: first encoder layer of a perturbed batch from the cached product plus rank-1 terms
+        # (False: the full pass over a copy of the data with the columns overwritten, as `perturbation` does)
+        self.screen_rank1 = True
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -346,3 +349,83 @@ class OntoVAE(nn.Module):
             raise ValueError("output must be 'terms' or 'genes'")
         res = self._pass_data(data, 'act' if output == 'terms' else 'rec')
         return self._subset_genes(ontobj, self._subset_terms(ontobj, res, terms), rec_genes)
+
+    def perturbation_screen(self, ontobj, dataset, perturbations, output='terms', direction='up', terms=None, rec_genes=None):
+        """A screen of many perturbations of one dataset: for each (genes, values) pair what `perturbation`
+        (vae_model.py:398-456) followed by Ontobj.wilcox_test against the unperturbed pass (ontobj.py:651-701) gives,
+        with the data, both activity matrices and the tests resident on the device.
+
+        The first encoder layer of the dataset is computed once; a perturbation adds one rank-1 term per gene to it
+        (ontovae_pass_data_perturbed) instead of repeating the [N, G] x [G, L] product.  Lists of more than 64 genes
+        take the ordinary pass over a copy of the data with the columns overwritten.
+
+        Returns {'stat', 'pval', 'qval'}: float64 arrays [len(perturbations), C], C = the selected terms (output=
+        'terms') or genes ('genes'), in the column order of get_pathway_activities / get_reconstructed_values; qval
+        is the Benjamini-Hochberg correction within each perturbation, over the selected columns."""
+        from . import stats as dstats
+        if output not in ('terms', 'genes'):
+            raise ValueError("output must be 'terms' or 'genes'")
+        e = self._engine
+        self.eval()
+        X = torch.as_tensor(self._dataset_copy(ontobj, dataset), dtype=torch.float32).to(e.device).contiguous()
+        N = X.shape[0]
+        Cn = e.plan.T if output == 'terms' else e.plan.G
+        step = int(self.inference_batch)
+        ld = max((N + 3) // 4 * 4, 4)
+        hpre = torch.empty(e.plan.L, ld if self.screen_rank1 else 4, dtype=torch.float32, device=e.device)
+        stage = torch.empty(min(step, max(N, 1)), Cn, dtype=torch.float32, device=e.device)
+        ctrl = torch.zeros(Cn, ld, dtype=torch.float32, device=e.device)
+        pert = torch.zeros(Cn, ld, dtype=torch.float32, device=e.device)
+        gene_pos = {g: i for i, g in enumerate(self.genes)}
+        out_key = 'act_out' if output == 'terms' else 'rec_out'
+
+        def run(dst, gidx, gval, data):
+            for i in range(0, N, step):
+                xb = data[i:i + step]
+                B = xb.shape[0]
+                kw = {out_key: stage[:B]}
+                if gidx is None:
+                    e.pass_data(xb, None, self._eps(B), self._eps(B), **kw)
+                else:
+                    e.pass_data_perturbed(xb, None, hpre, i, gidx, gval, self._eps(B), self._eps(B), **kw)
+                dstats.to_feature_major(stage[:B], dst, i)
+
+        rank1 = bool(self.screen_rank1)
+        if rank1:
+            for i in range(0, N, step):
+                e.encode_pre(X[i:i + step], None, hpre, i)
+            run(ctrl, np.zeros(0, np.int32), np.zeros(0, np.float32), X)
+        else:
+            run(ctrl, None, None, X)
+
+        P = len(perturbations)
+        stat = torch.empty(P, Cn, dtype=torch.float64, device=e.device)
+        pval = torch.empty(P, Cn, dtype=torch.float64, device=e.device)
+        alternative = 'greater' if direction == 'up' else 'less'
+        for p, (genes, values) in enumerate(perturbations):
+            last = {}
+            for g, v in zip(genes, values):                  # sequential overwrite: the last value of a repeated gene stays
+                if g not in gene_pos:
+                    raise ValueError(f"{g!r} is not in list")
+                last[gene_pos[g]] = float(v)
+            gidx = np.fromiter(last.keys(), dtype=np.int32, count=len(last))
+            gval = np.fromiter(last.values(), dtype=np.float32, count=len(last))
+            if rank1 and len(gidx) <= 64:
+                run(pert, gidx, gval, X)
+            else:
+                Xp = X.clone()
+                Xp[:, torch.as_tensor(gidx, dtype=torch.int64, device=e.device)] = torch.as_tensor(gval, device=e.device)
+                run(pert, None, None, Xp)
+            dstats.wilcoxon_zsplit(pert, ctrl, N, alternative, out=(stat[p], pval[p]))
+
+        cols = None
+        if output == 'terms' and terms is not None:
+            annot = ontobj.annot[self._key()]
+            cols = annot[annot.ID.isin(terms)].index.to_numpy()
+        if output == 'genes' and rec_genes is not None:
+            cols = np.array([gene_pos[g] for g in rec_genes])
+        if cols is not None:
+            ci = torch.as_tensor(cols, dtype=torch.int64, device=e.device)
+            stat, pval = stat[:, ci].contiguous(), pval[:, ci].contiguous()
+        qval = dstats.fdr_bh(pval) if P and pval.shape[1] else torch.empty_like(pval)
+        return {'stat': stat.cpu().numpy(), 'pval': pval.cpu().numpy(), 'qval': qval.cpu().numpy()}

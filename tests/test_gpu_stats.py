@@ -142,3 +142,110 @@ def test_wilcox_arrays_matches_reference_recipe():
     np.testing.assert_allclose(q, so.fdr_bh(p_ref), rtol=1e-10)
     stat_d, p_d, _ = dstats.wilcox_arrays(ctrl, pert, direction="down", device=DEV)
     np.testing.assert_allclose(p_d, so.wilcoxon_zsplit(pert, ctrl, "less")[1], rtol=P_RTOL)
+
+
+# ------------------------------------------------------------------------------ perturbation screen
+def _screen_model(N=300, seed=21):
+    from test_gpu_parity import make_model, medium
+    masks, sd = medium()
+    rng = np.random.default_rng(seed)
+    G = masks[-1].shape[0]
+    X = np.abs(rng.standard_normal((N, G))).astype(np.float32)
+    model, onto = make_model(masks, 3, sd, X=X)
+    L = model._engine.plan.L
+    eps = rng.standard_normal((64, N, L)).astype(np.float32)
+    return model, onto, X, eps
+
+
+def _replay(model, eps, N, step):
+    """eps_source that hands every pass over the dataset the same two draws per batch, pass after pass."""
+    state = {"call": 0}
+    nb = (N + step - 1) // step
+
+    def src(B):
+        c = state["call"]
+        state["call"] += 1
+        pass_no, within = divmod(c, 2 * nb)
+        b, which = divmod(within, 2)
+        return torch.as_tensor(eps[2 * pass_no + which, b * step: b * step + B])
+    model.eps_source = src
+    return state
+
+
+def test_pass_data_perturbed_equals_pass_over_overwritten_data():
+    """The rank-1 form of the first layer against the reference's recipe (overwrite the columns, run the pass):
+    activities and reconstruction to 1e-4 relative."""
+    from conftest import act_close
+    model, onto, X, eps = _screen_model()
+    e = model._engine
+    N, G = X.shape
+    model.eval()
+    Xd = torch.as_tensor(X, device=DEV)
+    hpre = torch.empty(e.plan.L, N + 4, device=DEV)
+    e.encode_pre(Xd, None, hpre, 0)
+    for genes, vals in (([], []), ([5], [0.0]), ([0, 17, 999], [3.0, 0.0, -1.5]), (list(range(100, 164)), [0.25] * 64)):
+        Xp = Xd.clone()
+        if genes:
+            Xp[:, genes] = torch.as_tensor(vals, device=DEV)
+        ref_act = torch.empty(N, e.plan.T, device=DEV)
+        ref_rec = torch.empty(N, G, device=DEV)
+        e.pass_data(Xp, None, eps[0], eps[1], act_out=ref_act, rec_out=ref_rec)
+        act = torch.empty(N, e.plan.T, device=DEV)
+        rec = torch.empty(N, G, device=DEV)
+        e.pass_data_perturbed(Xd, None, hpre, 0, genes, vals, eps[0], eps[1], act_out=act, rec_out=rec)
+        assert act_close(act.cpu().numpy(), ref_act.cpu().numpy())
+        assert act_close(rec.cpu().numpy(), ref_rec.cpu().numpy())
+    with pytest.raises(ValueError):
+        e.pass_data_perturbed(Xd, None, hpre, 0, [G], [1.0], eps[0], eps[1], act_out=act)
+    with pytest.raises(ValueError):
+        e.pass_data_perturbed(Xd, None, hpre, 0, [3, 3], [1.0, 2.0], eps[0], eps[1], act_out=act)
+    with pytest.raises(ValueError):
+        e.pass_data_perturbed(Xd, None, hpre, 0, list(range(65)), [0.0] * 65, eps[0], eps[1], act_out=act)
+
+
+@pytest.mark.parametrize("output", ["terms", "genes"])
+def test_screen_equals_perturbation_then_wilcox_test(output):
+    """perturbation_screen with the full pass per perturbation == the reference's loop: perturbation(...) per entry,
+    then scipy's test and the FDR on the host arrays (oracle), with the same eps per pass.  Statistic exact."""
+    model, onto, X, eps = _screen_model()
+    N = X.shape[0]
+    model.inference_batch = 128
+    names = model.genes
+    perts = [([names[3]], [0.0]), ([names[10], names[500], names[10]], [1.0, 0.0, 4.0]), ([names[i] for i in range(200, 270)], [0.0] * 70)]
+    model.screen_rank1 = False
+    _replay(model, eps, N, 128)
+    res = model.perturbation_screen(onto, "d", perts, output=output, direction="up")
+    _replay(model, eps, N, 128)
+    ctrl = model.get_pathway_activities(onto, "d") if output == "terms" else model.get_reconstructed_values(onto, "d")
+    for p, (genes, vals) in enumerate(perts):
+        arr = model.perturbation(onto, "d", genes, vals, output=output)
+        s_ref, p_ref = so.wilcoxon_zsplit(arr, ctrl, "greater")
+        np.testing.assert_array_equal(res["stat"][p], s_ref)
+        np.testing.assert_allclose(res["pval"][p], p_ref, rtol=P_RTOL)
+        np.testing.assert_allclose(res["qval"][p], so.fdr_bh(p_ref), rtol=1e-10)
+
+
+def test_screen_rank1_close_to_full_pass_and_subsets():
+    """The default (cached first layer + rank-1 terms) changes activities by float32 rounding only, so the rank sums
+    move by a few swaps of nearly tied differences at most; `terms` restricts the columns before the FDR."""
+    model, onto, X, eps = _screen_model()
+    N = X.shape[0]
+    names = model.genes
+    perts = [([names[3]], [0.0]), ([names[10], names[500]], [4.0, 0.0])]
+    out = {}
+    for rank1 in (False, True):
+        model.screen_rank1 = rank1
+        _replay(model, eps, N, model.inference_batch)
+        out[rank1] = model.perturbation_screen(onto, "d", perts, output="terms", direction="down")
+    total = N * (N + 1) / 2
+    assert np.abs(out[True]["stat"] - out[False]["stat"]).max() <= 0.002 * total
+    np.testing.assert_allclose(out[True]["pval"], out[False]["pval"], atol=0.02)
+    ids = list(onto.annot["1000_30"].ID[[1, 5, 40]])
+    _replay(model, eps, N, model.inference_batch)
+    sub_res = model.perturbation_screen(onto, "d", perts, output="terms", direction="down", terms=ids)
+    assert sub_res["pval"].shape == (2, 3)
+    np.testing.assert_array_equal(sub_res["pval"], out[True]["pval"][:, [1, 5, 40]])
+    for p in range(2):
+        np.testing.assert_allclose(sub_res["qval"][p], so.fdr_bh(sub_res["pval"][p]), rtol=1e-10)
+    with pytest.raises(ValueError):
+        model.perturbation_screen(onto, "d", [(["no such gene"], [0.0])])
