@@ -67,12 +67,55 @@ __device__ __forceinline__ u64 ov_wave_sum(u64 v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// n > 50: one workgroup per column; codes sorted in LDS (bitonic), ranks read off the sorted positions
+// n > 50: one workgroup of NT threads per column, E codes per thread in registers (n2 = NT * E >= n, padded with the
+// largest code).  Bitonic network over the index bits [wave | lane | register]:
+//   partner distance < E        compare-exchange between two registers of one thread;
+//   E <= distance < 64 E        between lanes of one wave (cross-lane read, no barrier);
+//   distance >= 64 E            between waves, through LDS (only log2(NT / 64) (log2(NT / 64) + 1) / 2 stages).
+// The sorted codes then go to LDS once and the ranks are read off their positions.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
+// median of three: med3(x, y, 0) = min(x, y), med3(x, y, ~0) = max(x, y) -- one instruction for a compare-exchange half
+// whose direction is only known at run time
+__device__ __forceinline__ uint32_t ov_med3(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+
+template <int E, int J>
+__device__ __forceinline__ void ov_bitonic_regs(uint32_t (&v)[E], uint32_t lo_sel, int k) {
+    // stages J, J/2, .. 1 inside the thread; direction from bit k of the element index t * E + r: a compile-time
+    // property of r while k < E, the thread's lo_sel (0: ascending, ~0: descending) from then on
+    if constexpr (J >= 1) {
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            if ((r & J) == 0) {
+                const uint32_t x = v[r], y = v[r | J];
+                if (k >= E) {
+                    v[r] = ov_med3(x, y, lo_sel);
+                    v[r | J] = ov_med3(x, y, ~lo_sel);
+                } else {
+                    const bool asc = (r & k) == 0;
+                    v[r] = asc ? min(x, y) : max(x, y);
+                    v[r | J] = asc ? max(x, y) : min(x, y);
+                }
+            }
+        ov_bitonic_regs<E, J / 2>(v, lo_sel, k);
+    }
+}
+// merges of length 2, 4, .. E inside the thread
+template <int E, int K>
+__device__ __forceinline__ void ov_bitonic_thread_sort(uint32_t (&v)[E], int t) {
+    if constexpr (K <= E) {
+        ov_bitonic_regs<E, K / 2>(v, (t & 1) ? 0xFFFFFFFFu : 0u, K);
+        ov_bitonic_thread_sort<E, K * 2>(v, t);
+    }
+}
+
+template <int NT, int E>
 __global__ __launch_bounds__(NT) void ov_wilcoxon_sort_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t ld,
-                                                              int n, int n2, int alt, double* __restrict__ stat,
-                                                              double* __restrict__ pval) {
+                                                              int n, int alt, double* __restrict__ stat, double* __restrict__ pval) {
+    constexpr int N2 = NT * E;
     extern __shared__ uint32_t codes[];
     __shared__ u64 red[3][NT / 64];
     __shared__ int s_nan;
@@ -81,17 +124,49 @@ __global__ __launch_bounds__(NT) void ov_wilcoxon_sort_kernel(const float* __res
     const float* pb = b + (int64_t)col * ld;
     if (tid == 0) s_nan = 0;
     bool nan = false;
-    for (int i = tid; i < n2; i += NT) codes[i] = i < n ? ov_wx_code(pa[i] - pb[i], &nan) : 0xFFFFFFFFu;
-    for (int k = 2; k <= n2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < (n2 >> 1); t += NT) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-                const uint32_t x = codes[i], y = codes[p];
-                if ((x > y) == ((i & k) == 0)) { codes[i] = y; codes[p] = x; }
+    uint32_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {            // the input order is irrelevant: coalesced loads
+        const int i = r * NT + tid;
+        v[r] = i < n ? ov_wx_code(pa[i] - pb[i], &nan) : 0xFFFFFFFFu;
+    }
+    ov_bitonic_thread_sort<E, 2>(v, tid);
+#pragma unroll 1
+    for (int k = 2 * E; k <= N2; k <<= 1) {
+        const bool asc = ((tid * E) & k) == 0;
+        int j = k >> 1;
+#pragma unroll 1
+        for (; j >= 4 * E; j >>= 1) {
+            const int m = j / E;                                  // partner thread = tid ^ m
+            const uint32_t sel = (((tid & m) == 0) == asc) ? 0u : 0xFFFFFFFFu;     // 0: keep the smaller one
+            if (m >= 64) {                                        // other wave: through LDS
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) codes[r * NT + tid] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) v[r] = ov_med3(v[r], codes[r * NT + (tid ^ m)], sel);
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) v[r] = ov_med3(v[r], (uint32_t)__shfl_xor((int)v[r], m, 64), sel);
             }
         }
+        if (j == 2 * E) {                                         // partner lane ^ 2: DPP quad_perm [2, 3, 0, 1]
+            const uint32_t sel = (((tid & 2) == 0) == asc) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[r] = ov_med3(v[r], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[r], 0x4E, 0xF, 0xF, true), sel);
+        }
+        {                                                         // partner lane ^ 1: DPP quad_perm [1, 0, 3, 2]
+            const uint32_t sel = (((tid & 1) == 0) == asc) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[r] = ov_med3(v[r], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[r], 0xB1, 0xF, 0xF, true), sel);
+        }
+        ov_bitonic_regs<E, E / 2>(v, asc ? 0u : 0xFFFFFFFFu, k);
+    }
+    __syncthreads();
     if (nan) s_nan = 1;
+#pragma unroll
+    for (int r = 0; r < E; ++r) codes[tid * E + r] = v[r];
     __syncthreads();
     u64 plus4 = 0, zero4 = 0, tie = 0;
     for (int i = tid; i < n; i += NT) {
@@ -342,16 +417,22 @@ extern "C" int ontovae_wilcoxon_zsplit(const float* perturbed, const float* cont
         return ONTOVAE_OK;
     }
     if (n <= OV_WX_LDS_MAX) {
-        int n2 = 64;
-        while (n2 < n) n2 <<= 1;
-        const size_t lds = (size_t)n2 * 4;
         int rc;
-        if (n2 <= 2048) {
-            hipLaunchKernelGGL(ov_wilcoxon_sort_kernel<256>, dim3(ncols), dim3(256), lds, st, perturbed, control, ld, n, n2, alternative, stat, pval);
-        } else {
-            if ((rc = ov_stats_allow_lds(reinterpret_cast<const void*>(ov_wilcoxon_sort_kernel<1024>), lds))) return rc;
-            hipLaunchKernelGGL(ov_wilcoxon_sort_kernel<1024>, dim3(ncols), dim3(1024), lds, st, perturbed, control, ld, n, n2, alternative, stat, pval);
-        }
+#define OV_WX_LAUNCH(NT, E)                                                                                                   \
+        do {                                                                                                                  \
+            if ((rc = ov_stats_allow_lds(reinterpret_cast<const void*>(ov_wilcoxon_sort_kernel<NT, E>), (size_t)NT * E * 4))) return rc; \
+            hipLaunchKernelGGL((ov_wilcoxon_sort_kernel<NT, E>), dim3(ncols), dim3(NT), (size_t)NT * E * 4, st, perturbed, control, ld, n, \
+                               alternative, stat, pval);                                                                      \
+        } while (0)
+        if (n <= 256) OV_WX_LAUNCH(256, 1);
+        else if (n <= 512) OV_WX_LAUNCH(256, 2);
+        else if (n <= 1024) OV_WX_LAUNCH(256, 4);
+        else if (n <= 2048) OV_WX_LAUNCH(256, 8);
+        else if (n <= 4096) OV_WX_LAUNCH(256, 16);
+        else if (n <= 8192) OV_WX_LAUNCH(1024, 8);
+        else if (n <= 16384) OV_WX_LAUNCH(1024, 16);
+        else OV_WX_LAUNCH(1024, 32);
+#undef OV_WX_LAUNCH
         OV_LAUNCH_CHECK();
         return ONTOVAE_OK;
     }
