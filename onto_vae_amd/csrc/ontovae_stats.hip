@@ -139,7 +139,21 @@ __global__ __launch_bounds__(NT) void ov_wilcoxon_sort_kernel(const float* __res
         for (; j >= 4 * E; j >>= 1) {
             const int m = j / E;                                  // partner thread = tid ^ m
             const uint32_t sel = (((tid & m) == 0) == asc) ? 0u : 0xFFFFFFFFu;     // 0: keep the smaller one
-            if (m >= 64) {                                        // other wave: through LDS
+            if (m == 8) {                 // lane ^ 8 inside a row of 16: two DPP row shifts, each writing its half of the banks
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    int o = __builtin_amdgcn_update_dpp(0, (int)v[r], 0x108, 0xF, 0x3, false);       // row_shl:8 -> lanes 0..7 of the row
+                    o = __builtin_amdgcn_update_dpp(o, (int)v[r], 0x118, 0xF, 0xC, false);           // row_shr:8 -> lanes 8..15
+                    v[r] = ov_med3(v[r], (uint32_t)o, sel);
+                }
+            } else if (m == 4) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    int o = __builtin_amdgcn_update_dpp(0, (int)v[r], 0x104, 0xF, 0x5, false);       // row_shl:4 -> banks 0 and 2
+                    o = __builtin_amdgcn_update_dpp(o, (int)v[r], 0x114, 0xF, 0xA, false);           // row_shr:4 -> banks 1 and 3
+                    v[r] = ov_med3(v[r], (uint32_t)o, sel);
+                }
+            } else if (m >= 64) {                                        // other wave: through LDS
                 __syncthreads();
 #pragma unroll
                 for (int r = 0; r < E; ++r) codes[r * NT + tid] = v[r];
