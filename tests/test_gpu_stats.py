@@ -249,3 +249,33 @@ def test_screen_rank1_close_to_full_pass_and_subsets():
         np.testing.assert_allclose(sub_res["qval"][p], so.fdr_bh(sub_res["pval"][p]), rtol=1e-10)
     with pytest.raises(ValueError):
         model.perturbation_screen(onto, "d", [(["no such gene"], [0.0])])
+
+
+def test_wilcox_test_dataframe_like_the_reference():
+    """Ontobj.wilcox_test (ontobj.py:678-701): columns, row order (sorted by pval) and values of the result frame."""
+    import pandas as pd
+
+    class Onto:          # the two accessors wilcox_test calls on the reference's Ontobj
+        def __init__(self, n):
+            self._annot = pd.DataFrame({"ID": [f"T:{i}" for i in range(n)], "Name": [f"term {i}" for i in range(n)], "depth": [i % 5 for i in range(n)]})
+
+        def extract_annot(self, top_thresh=1000, bottom_thresh=30):
+            return self._annot
+
+        def extract_genes(self, top_thresh=1000, bottom_thresh=30):
+            return [f"G{i}" for i in range(len(self._annot))]
+
+    rng = np.random.default_rng(12)
+    ctrl, pert = _pair(rng, 120, 25, "plain")
+    s_ref, p_ref = so.wilcoxon_zsplit(pert, ctrl, "greater")
+    q_ref = so.fdr_bh(p_ref)
+    order = np.argsort(p_ref, kind="stable")
+    res = dstats.wilcox_test(Onto(25), ctrl, pert, direction="up", option="terms", device=DEV)
+    assert list(res.columns) == ["id", "term", "depth", "stat", "pval", "qval"]
+    assert list(res["id"]) == [f"T:{i}" for i in order]
+    np.testing.assert_array_equal(res["stat"].to_numpy(), s_ref[order])
+    np.testing.assert_allclose(res["pval"].to_numpy(), p_ref[order], rtol=P_RTOL)
+    np.testing.assert_allclose(res["qval"].to_numpy(), q_ref[order], rtol=1e-10)
+    res_g = dstats.wilcox_test(Onto(25), ctrl, pert, direction="down", option="genes", device=DEV)
+    assert list(res_g.columns) == ["gene", "stat", "pval", "qval"] and len(res_g) == 25
+    assert (np.diff(res_g["pval"].to_numpy()) >= 0).all()
