@@ -196,8 +196,9 @@ def screen_bench(a, model, dev, world, rank):
             e.pass_data(X, None, None, None, act_out=stage)
             X[:, g] = col
         else:
-            e.pass_data_perturbed(X, None, hpre, 0, np.array([g], np.int32), zero, None, None, act_out=stage)
-        dstats.to_feature_major(stage, pert)
+            e.pass_data_perturbed(X, None, hpre, 0, np.array([g], np.int32), zero, None, None, act_fm=pert)
+        if full:
+            dstats.to_feature_major(stage, pert)
         dstats.wilcoxon_zsplit(pert, ctrl, N, "greater", out=(stat[i % P], pval[i % P]))
         it[0] += 1
 

@@ -297,15 +297,17 @@ int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const int32_t* x
  * the screen.  ontovae_pass_data_perturbed is ontovae_pass_data on the UNPERTURBED x plus that cache and the lists
  * pert_gene / pert_val (HOST arrays, n_pert <= ONTOVAE_MAX_PERTURBED_GENES distinct column indices): the encoder GEMM,
  * three quarters of the time of a pass, is replaced by the rank-1 terms.  Outputs as ontovae_pass_data; they agree with
- * a pass over the overwritten data to float32 rounding of the first layer (tests: 1e-4 relative). */
+ * a pass over the overwritten data to float32 rounding of the first layer (tests: 1e-4 relative).
+ * act_feature_major != 0: act_out is written as act_out[t * act_ld + b] (act_ld >= B), the layout
+ * ontovae_wilcoxon_zsplit reads, so a screen needs no transposition between the pass and the test. */
 #define ONTOVAE_MAX_PERTURBED_GENES 64
 int ontovae_encode_pre(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, float* hpre,
                        int64_t ldh, void* stream);
 int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B,
                                 const float* hpre, int64_t ldh, int32_t n_pert, const int32_t* pert_gene,
                                 const float* pert_val, const float* eps1, const float* eps2,
-                                uint64_t rng_offset, float* act_out, int64_t act_ld, float* rec_out,
-                                int64_t rec_ld, void* stream);
+                                uint64_t rng_offset, float* act_out, int64_t act_ld, int32_t act_feature_major,
+                                float* rec_out, int64_t rec_ld, void* stream);
 
 /* OntoDecoder.forward alone (onto_vae/modules.py:303-313) on a caller-supplied z [B, L]:
  * the "decoder-only sparse throughput" leg of the inference benchmark. */

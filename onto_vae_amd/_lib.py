@@ -99,7 +99,7 @@ def lib():
         "ontovae_pass_data": [C.POINTER(Ctx), vp, vp, i32, vp, vp, u64, vp, i64, vp, i64, vp],
         "ontovae_decoder_forward": [C.POINTER(Ctx), vp, i32, vp, i64, vp, i64, vp],
         "ontovae_encode_pre": [C.POINTER(Ctx), vp, vp, i32, vp, i64, vp],
-        "ontovae_pass_data_perturbed": [C.POINTER(Ctx), vp, vp, i32, vp, i64, i32, c_i32p, c_f32p, vp, vp, u64, vp, i64, vp, i64, vp],
+        "ontovae_pass_data_perturbed": [C.POINTER(Ctx), vp, vp, i32, vp, i64, i32, c_i32p, c_f32p, vp, vp, u64, vp, i64, i32, vp, i64, vp],
         "ontovae_compose_order": [vp, vp, vp, i64, vp],
         "ontovae_gather_rows": [vp, i64, vp, i32, i32, vp, vp],
         "ontovae_vals_to_dense": [vp, vp, vp, i64, i64, vp, i64, vp],

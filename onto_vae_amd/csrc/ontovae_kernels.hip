@@ -1774,6 +1774,22 @@ __global__ __launch_bounds__(256) void ov_act_out_levels_kernel(const float* __r
     }
 }
 
+// The same, feature-major: out[c * ld_out + b] (the layout the Wilcoxon kernel reads), no transposition needed
+__global__ __launch_bounds__(256) void ov_act_fm_levels_kernel(const float* __restrict__ act, const OvActLevels lv, int c_begin, int c_end,
+                                                              int nu, int B, int ldb, float* __restrict__ out, int64_t ld_out) {
+    const int c = c_begin + blockIdx.y, b = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= c_end || b >= B) return;
+    int l = 0;
+    while (l + 1 < lv.n && c >= lv.tstart[l + 1]) ++l;
+    const float* src = act + (int64_t)(lv.node0[l] + (c - lv.tstart[l]) * nu) * ldb + b;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < nu; ++a) s += *reinterpret_cast<const f32x4*>(src + (int64_t)a * ldb);
+    float* dst = out + (int64_t)c * ld_out + b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (b + j < B) dst[j] = s[j] / (float)nu;
+}
+
 __global__ void ov_compose_order_kernel(const int32_t* __restrict__ in, const int64_t* __restrict__ perm,
                                         int32_t* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2356,8 +2372,9 @@ extern "C" int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const
     return ov_loss_finalize(s, s.st, ov_nrec(s), nkl, kl_coeff, loss_out);
 }
 
-static int ov_act_out(OvStep& s, int lvl_from, int lvl_to, float* act_out, int64_t act_ld) {
+static int ov_act_out(OvStep& s, int lvl_from, int lvl_to, float* act_out, int64_t act_ld, bool feature_major = false) {
     const ontovae_dims_t& d = s.c->dims;
+    if (feature_major && d.K > OV_MAX_LEVELS) { ontovae_set_error("feature-major activities need K <= %d levels", OV_MAX_LEVELS); return ONTOVAE_EINVAL; }
     if (d.K <= OV_MAX_LEVELS) {          // one launch for the whole range of levels
         OvActLevels lv;
         lv.n = d.K;
@@ -2370,6 +2387,12 @@ static int ov_act_out(OvStep& s, int lvl_from, int lvl_to, float* act_out, int64
         lv.tstart[d.K] = t0;
         const int c0 = lv.tstart[std::max(lvl_from, 0)], c1 = lv.tstart[std::min(lvl_to, (int)d.K)];
         if (c1 <= c0) return ONTOVAE_OK;
+        if (feature_major) {
+            hipLaunchKernelGGL(ov_act_fm_levels_kernel, dim3((s.B + 1023) / 1024, c1 - c0), dim3(256), 0, s.st, s.ws.act, lv, c0, c1, d.nu, s.B,
+                               s.ldb, act_out, act_ld);
+            OV_LAUNCH_CHECK();
+            return ONTOVAE_OK;
+        }
         dim3 grid((c1 - c0 + 31) / 32, (s.B + 31) / 32);
         hipLaunchKernelGGL(ov_act_out_levels_kernel, grid, dim3(256), 0, s.st, s.ws.act, lv, c0, c1, d.nu, s.B, s.ldb, act_out, act_ld);
         OV_LAUNCH_CHECK();
@@ -2467,7 +2490,7 @@ extern "C" int ontovae_encode_pre(const ontovae_ctx_t* ctx, const float* x, cons
 extern "C" int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* hpre,
                                            int64_t ldh, int32_t n_pert, const int32_t* pert_gene, const float* pert_val,
                                            const float* eps1, const float* eps2, uint64_t rng_offset, float* act_out, int64_t act_ld,
-                                           float* rec_out, int64_t rec_ld, void* stream) {
+                                           int32_t act_feature_major, float* rec_out, int64_t rec_ld, void* stream) {
     int rc = ov_check_ctx(ctx, B, false);
     if (rc) return rc;
     const ontovae_dims_t& d = ctx->dims;
@@ -2476,7 +2499,9 @@ extern "C" int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float
         ontovae_set_error("pass_data_perturbed: n_pert = %d outside [0, %d] or NULL lists", n_pert, OV_PERT_MAX);
         return ONTOVAE_EINVAL;
     }
-    if ((act_out && act_ld < d.T) || (rec_out && rec_ld < d.G)) { ontovae_set_error("pass_data_perturbed: output leading dimension too small"); return ONTOVAE_EINVAL; }
+    const bool fm = act_feature_major != 0;
+    if ((act_out && act_ld < (fm ? B : d.T)) || (rec_out && rec_ld < d.G)) { ontovae_set_error("pass_data_perturbed: output leading dimension too small"); return ONTOVAE_EINVAL; }
+    if (fm && act_out && ((reinterpret_cast<uintptr_t>(act_out) & 3) != 0)) { ontovae_set_error("pass_data_perturbed: act_out misaligned"); return ONTOVAE_EINVAL; }
     OvPert pt{};
     pt.n = n_pert;
     for (int p = 0; p < n_pert; ++p) {
@@ -2494,10 +2519,10 @@ extern "C" int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float
     if ((rc = ov_bn_fwd(s, 1, 0, s.B, nullptr, rng_offset))) return rc;
     if ((rc = ov_heads_fwd(s))) return rc;
     if ((rc = ov_reparam(s, eps1, 0, rng_offset, OV_RNG_EPS, 0, nullptr, true))) return rc;
-    if (act_out && (rc = ov_act_out(s, 0, 1, act_out, act_ld))) return rc;
+    if (act_out && (rc = ov_act_out(s, 0, 1, act_out, act_ld, fm))) return rc;
     if ((rc = ov_reparam(s, eps2, 0, rng_offset, OV_RNG_EPS2, 0, nullptr, false))) return rc;
     if ((rc = ov_dec_forward_terms(s, true))) return rc;
-    if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld))) return rc;
+    if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld, fm))) return rc;
     if (rec_out && (rc = ov_dec_gene<2>(s, rec_out, rec_ld))) return rc;
     return ONTOVAE_OK;
 }

@@ -337,8 +337,10 @@ class Engine:
         _lib.check(_lib.lib().ontovae_encode_pre(C.byref(ctx), _ptr(x), _ptr(xidx), B, C.c_void_p(hpre.data_ptr() + 4 * col0),
                                                  hpre.stride(0), self.stream()), "encode_pre")
 
-    def pass_data_perturbed(self, x, xidx, hpre, col0, genes, values, eps1, eps2, act_out=None, rec_out=None):
-        """pass_data of the batch with columns `genes` of x replaced by `values`, from the cache encode_pre filled."""
+    def pass_data_perturbed(self, x, xidx, hpre, col0, genes, values, eps1, eps2, act_out=None, rec_out=None, act_fm=None, act_fm_col0=0):
+        """pass_data of the batch with columns `genes` of x replaced by `values`, from the cache encode_pre filled.
+        act_fm: feature-major [T, ld] matrix whose columns [act_fm_col0, act_fm_col0 + B) receive the activities
+        (instead of the sample-major act_out)."""
         x, xidx, B = self._x(x, xidx)
         eps1, eps2 = self._eps(eps1, B), self._eps(eps2, B)
         genes = np.ascontiguousarray(genes, dtype=np.int32)
@@ -346,10 +348,19 @@ class Engine:
         if genes.ndim != 1 or genes.shape != values.shape:
             raise ValueError("genes and values must be 1-D and of equal length")
         ctx = self.ctx(B)
+        if act_fm is not None:
+            if act_out is not None:
+                raise ValueError("give act_out or act_fm, not both")
+            if act_fm.dtype != torch.float32 or act_fm.dim() != 2 or act_fm.shape[0] != self.plan.T or act_fm.stride(1) != 1 or \
+                    act_fm_col0 < 0 or act_fm_col0 + B > act_fm.shape[1]:
+                raise ValueError(f"act_fm must be float32 [{self.plan.T}, >= {act_fm_col0 + B}]")
+            aptr, ald, afm = C.c_void_p(act_fm.data_ptr() + 4 * act_fm_col0), act_fm.stride(0), 1
+        else:
+            aptr, ald, afm = _ptr(act_out), act_out.stride(0) if act_out is not None else 0, 0
         _lib.check(_lib.lib().ontovae_pass_data_perturbed(
             C.byref(ctx), _ptr(x), _ptr(xidx), B, C.c_void_p(hpre.data_ptr() + 4 * col0), hpre.stride(0), len(genes),
             genes.ctypes.data_as(_lib.c_i32p), values.ctypes.data_as(_lib.c_f32p), _ptr(eps1), _ptr(eps2), self.next_offset(),
-            _ptr(act_out), act_out.stride(0) if act_out is not None else 0, _ptr(rec_out),
+            aptr, ald, afm, _ptr(rec_out),
             rec_out.stride(0) if rec_out is not None else 0, self.stream()), "pass_data_perturbed")
 
     def decoder_forward(self, z, act_out=None, rec_out=None):

@@ -386,6 +386,9 @@ class OntoVAE(nn.Module):
                 kw = {out_key: stage[:B]}
                 if gidx is None:
                     e.pass_data(xb, None, self._eps(B), self._eps(B), **kw)
+                elif output == 'terms':          # activities straight into their columns of the feature-major matrix
+                    e.pass_data_perturbed(xb, None, hpre, i, gidx, gval, self._eps(B), self._eps(B), act_fm=dst, act_fm_col0=i)
+                    continue
                 else:
                     e.pass_data_perturbed(xb, None, hpre, i, gidx, gval, self._eps(B), self._eps(B), **kw)
                 dstats.to_feature_major(stage[:B], dst, i)

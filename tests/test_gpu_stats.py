@@ -195,6 +195,10 @@ def test_pass_data_perturbed_equals_pass_over_overwritten_data():
         e.pass_data_perturbed(Xd, None, hpre, 0, genes, vals, eps[0], eps[1], act_out=act, rec_out=rec)
         assert act_close(act.cpu().numpy(), ref_act.cpu().numpy())
         assert act_close(rec.cpu().numpy(), ref_rec.cpu().numpy())
+        # the same activities written feature-major into columns [4, 4 + N) of a wider matrix
+        fm = torch.full((e.plan.T, N + 9), -7.0, device=DEV)
+        e.pass_data_perturbed(Xd, None, hpre, 0, genes, vals, eps[0], eps[1], act_fm=fm, act_fm_col0=4)
+        assert torch.equal(fm[:, 4:4 + N], act.t()) and (fm[:, :4] == -7.0).all() and (fm[:, 4 + N:] == -7.0).all()
     with pytest.raises(ValueError):
         e.pass_data_perturbed(Xd, None, hpre, 0, [G], [1.0], eps[0], eps[1], act_out=act)
     with pytest.raises(ValueError):
