@@ -332,7 +332,7 @@ def test_dp_phases_equal_fused_step():
     assert torch.equal(ranks[0]._engine.P, ranks[1]._engine.P)
 
 
-@pytest.mark.parametrize("parts", [[(0, 40), (40, 96)], [(0, 70), (70, 140), (140, 209)]])
+@pytest.mark.parametrize("parts", [[(0, 40), (40, 96)], [(0, 70), (70, 140), (140, 209)], [(128 * r, 128 * r + 128) for r in range(8)]])
 def test_dp_gathered_dh_equals_fused_step(parts):
     """The data-parallel step without an all-reduce of dW0: simulated ranks on one GPU, collectives by hand.  Every
     rank forms dW0 of the GLOBAL batch from the all-gathered dh blocks (ontovae_dp_bn_bwd, ontovae_dw0_global; global
@@ -368,10 +368,15 @@ def test_dp_gathered_dh_equals_fused_step(parts):
     louts = [torch.zeros(3, device="cuda") for _ in ranks]
     for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
         m._engine.train_step_dp(0, x[a:b], None, B, eps[a:b], kc, stats[r], bstats[r], louts[r], 1)
-    g = combine_bn_stats(torch.stack(stats), torch.tensor([b - a for a, b in parts], device="cuda", dtype=torch.float32))
-    for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
-        stats[r].copy_(g)
-        m._engine.train_step_dp(1, x[a:b], None, B, eps[a:b], kc, stats[r], bstats[r], louts[r], 1)
+    if R == 8:      # the shape of `bench.py --gpus 8`: 8 chunks of the K loop, and the statistics combined inside the BatchNorm kernel
+        stats_all = torch.cat([torch.cat([stats[r].reshape(-1), torch.tensor([float(b - a)], device="cuda")]) for r, (a, b) in enumerate(parts)])
+        for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+            m._engine.train_step_dp(16 + R, x[a:b], None, B, eps[a:b], kc, stats_all, bstats[r], louts[r], 1)
+    else:
+        g = combine_bn_stats(torch.stack(stats), torch.tensor([b - a for a, b in parts], device="cuda", dtype=torch.float32))
+        for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+            stats[r].copy_(g)
+            m._engine.train_step_dp(1, x[a:b], None, B, eps[a:b], kc, stats[r], bstats[r], louts[r], 1)
     bsum = sum(bstats)
     lay = ranks[0]._engine.plan.layout
     early = slice(int(lay.Wh), int(lay.total))
