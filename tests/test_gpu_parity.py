@@ -496,3 +496,25 @@ def test_gobp_syn_full_size_vs_oracle():
     check_params({"gene": got_vals[k0:k1], "W0": e.view("W0").cpu().numpy()},
                  {"gene": want_vals, "W0": o.p["encoder.encoder.0.0.weight"]}, 2e-4, rtol=2e-4, atol=2e-6, outliers=0.01)
     assert got_vals.min() >= 0.0
+
+
+def test_inference_batch_variants_agree_with_small_batches():
+    """Inference batches take other kernels than training-size ones (elementwise eval BatchNorm and unsplit heads from 1024
+    columns, 64-wide activity tiles, one launch per level from 2048): a pass over 2300 rows in one batch must give what
+    the same rows give in batches of 500 (each row is independent in eval mode)."""
+    masks, sd = medium()
+    rng = np.random.RandomState(3)
+    N, L = 2300, 60
+    X = np.log1p(rng.poisson(0.5, size=(N, 1000))).astype(np.float32)
+    model, onto = make_model(masks, 3, sd, X=X)
+    e1, e2 = rng.standard_normal((N, L)).astype(np.float32), rng.standard_normal((N, L)).astype(np.float32)
+    out = {}
+    for step in (500, 1100, 4096):
+        model.inference_batch = step
+        chunks = [(i, min(i + step, N)) for i in range(0, N, step)]
+        for what in ("act", "rec"):
+            feed(model, [v for a, b in chunks for v in (e1[a:b], e2[a:b])])
+            out[step, what] = model.get_pathway_activities(onto, "d") if what == "act" else model.get_reconstructed_values(onto, "d")
+    for step in (1100, 4096):
+        assert act_close(out[step, "act"], out[500, "act"])
+        assert act_close(out[step, "rec"], out[500, "rec"])
