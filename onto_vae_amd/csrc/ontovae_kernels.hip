@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict_
 }
 
 // Eval mode (running statistics) at inference batch sizes: plain elementwise work over the whole [L, ldb] matrix instead of
-// one wave walking a feature's row.  Same operations in the same order as mode 0 above (S <= 4: one slab per wave there).
+// one wave walking a feature's row.  Same operations in the same order as mode 0 above (S <= 12: wave z there adds slabs
+// z, z + 4, z + 8 one after the other).
 __global__ __launch_bounds__(256) void ov_bn_eval_kernel(const float* __restrict__ slab, int S, int64_t slab_stride,
                                                         const float* __restrict__ b0, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ rmean,
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void ov_bn_eval_kernel(const float* __restrict
 #pragma unroll
     for (int z = 0; z < 4; ++z) {
         p[z] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (z < S) p[z] += *reinterpret_cast<const f32x4*>(src + (int64_t)z * slab_stride);
+        for (int q = z; q < S; q += 4) p[z] += *reinterpret_cast<const f32x4*>(src + (int64_t)q * slab_stride);
     }
     f32x4 h4 = (p[0] + p[1]) + (p[2] + p[3]);
     const float bias = b0[l], mean = rmean[l], invstd = 1.0f / sqrtf(rvar[l] + 1e-5f), g = gamma[l], be = beta[l];
@@ -2031,7 +2032,7 @@ static int ov_bn_fwd(OvStep& s, int S, int mode, int Bglobal, float* stats, uint
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     OvProfScope prof(ONTOVAE_PHASE_BN_FWD, s.st);
-    if (mode == 0 && S <= 4 && s.ldb >= 1024) {
+    if (mode == 0 && S <= 12 && s.ldb >= 1024) {
         hipLaunchKernelGGL(ov_bn_eval_kernel, dim3((s.ldb / 4 + 255) / 256, d.L), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb,
                            c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, s.ws.a, s.B, s.ldb);
         OV_LAUNCH_CHECK();
