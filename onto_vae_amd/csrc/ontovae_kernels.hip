@@ -596,6 +596,89 @@ __device__ __forceinline__ void ov_stv(float* p, const float (&v)[VEC]) {
     *reinterpret_cast<VT*>(p) = t;
 }
 
+// Term level of a screen pass (inference batch, activities wanted feature-major): one wave per TERM.  The NU neurons of a
+// term have the same child list (every term-to-term link is a dense NU x NU block, modules.py:268-275), so the wave
+// reads each child row once for NU accumulators, stores the NU rows of the panel, and writes their mean
+// (vae_model.py:317) straight to the activity matrix: the separate output kernel, which re-reads the whole panel, is not
+// needed.  Same summation order per row as ov_dec_fwd_kernel.  A term whose rows do not share one list (never
+// produced by the packer; checked from the index lists) is done row by row.
+template <int VEC, int NU>
+__global__ __launch_bounds__(256) void ov_dec_fwd_term_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                             const float* __restrict__ vals, const float* __restrict__ bias,
+                                                             float* __restrict__ act, int node_begin, int node_end, int B, int ldb,
+                                                             float* __restrict__ fm_out, int64_t fm_ld, int c_base) {
+    const int term = blockIdx.x * 4 + ov_wave_id();
+    const int node = node_begin + term * NU;
+    const int b0 = blockIdx.y * (64 * VEC) + ov_lane() * VEC;
+    if (node >= node_end) return;
+    int k0[NU];
+    const int len = rowptr[node + 1] - rowptr[node];
+    bool same = true;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+        k0[a] = rowptr[node + a];
+        same = same && (rowptr[node + a + 1] - k0[a] == len);
+    }
+    if (same)
+        for (int i = 0; i < len; ++i)
+#pragma unroll
+            for (int a = 1; a < NU; ++a) same = same && (colidx[k0[a] + i] == colidx[k0[0] + i]);
+    float acc[NU][VEC];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+        const float bv = bias[node + a];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[a][j] = bv;
+    }
+    if (same) {
+        int i = 0;
+        for (; i + 2 <= len; i += 2) {
+            float v0[VEC], v1[VEC];
+            ov_ldv<VEC>(act + (int64_t)colidx[k0[0] + i] * ldb + b0, v0);
+            ov_ldv<VEC>(act + (int64_t)colidx[k0[0] + i + 1] * ldb + b0, v1);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                const float w0 = vals[k0[a] + i], w1 = vals[k0[a] + i + 1];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    acc[a][j] += w0 * v0[j];
+                    acc[a][j] += w1 * v1[j];
+                }
+            }
+        }
+        if (i < len) {
+            float v0[VEC];
+            ov_ldv<VEC>(act + (int64_t)colidx[k0[0] + i] * ldb + b0, v0);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                const float w0 = vals[k0[a] + i];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[a][j] += w0 * v0[j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < NU; ++a)
+            for (int k = k0[a]; k < rowptr[node + a + 1]; ++k) {
+                float v0[VEC];
+                const float w0 = vals[k];
+                ov_ldv<VEC>(act + (int64_t)colidx[k] * ldb + b0, v0);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[a][j] += w0 * v0[j];
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < NU; ++a) ov_stv<VEC>(act + (int64_t)(node + a) * ldb + b0, acc[a]);
+    float* dst = fm_out + (int64_t)(c_base + term) * fm_ld + b0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        float m = 0.f;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) m += acc[a][j];          // the order of ov_act_fm_levels_kernel
+        if (b0 + j < B) dst[j] = m / (float)NU;
+    }
+}
+
 // GENE: 0 = term level (write ACT), 1 = gene level training (D + loss partials), 2 = gene level
 // inference (recon sample-major to rec_out)
 template <int VEC, int GENE>
@@ -1951,6 +2034,8 @@ struct OvStep {
     int64_t xld;
     int heads_S;             // split-K slabs the heads GEMM left in ws.slab (0: mu / log_var are already in ws.mulv)
     struct OvSide* side;     // internal second stream of this device, or NULL (ONTOVAE_FLAG_SINGLE_STREAM / creation failed)
+    float* fm_out;           // screen passes: feature-major activity matrix the term levels write their nu-means to, or NULL
+    int64_t fm_ld;
 };
 
 // Independent branches of a step run on a library-owned second stream, forked from and joined back into
@@ -2110,6 +2195,16 @@ static int ov_dec_fwd_level(OvStep& s, int nb, int ne, float* rec_out, int64_t r
     const float* vals = c->P + c->lay.dec_vals;
     const float* bias = c->P + c->lay.dec_bias;
     OvProfScope prof(GENE ? ONTOVAE_PHASE_DEC_FWD_GENE : ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
+    if (GENE == 0 && s.fm_out) {          // ov_fm_fused(s) held: see ontovae_pass_data_perturbed
+        int c_base = 0;
+        for (int lvl = 0; lvl < d.K && c->level_begin[lvl] != nb; ++lvl) c_base += (c->level_end[lvl] - c->level_begin[lvl]) / d.nu;
+        const dim3 tgrid(((ne - nb) / d.nu + 3) / 4, s.nchunk);
+#define OV_DT(NU) hipLaunchKernelGGL((ov_dec_fwd_term_kernel<4, NU>), tgrid, dim3(256), 0, s.st, c->rowptr, c->colidx, vals, bias, s.ws.act, nb, ne, s.B, s.ldb, s.fm_out, s.fm_ld, c_base)
+        if (d.nu == 2) OV_DT(2); else if (d.nu == 3) OV_DT(3); else OV_DT(4);
+#undef OV_DT
+        OV_LAUNCH_CHECK();
+        return ONTOVAE_OK;
+    }
 #define OV_DF(V)                                                                                                        \
     hipLaunchKernelGGL((ov_dec_fwd_kernel<V, GENE>), grid, dim3(256), 0, s.st, c->rowptr, c->colidx, vals, bias, s.ws.act, \
                        nb, ne, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C)
@@ -2318,6 +2413,8 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->xld = ctx->dims.G;
     s->heads_S = 0;
     s->side = nullptr;
+    s->fm_out = nullptr;
+    s->fm_ld = 0;
     return ONTOVAE_OK;
 }
 
@@ -2473,6 +2570,16 @@ __global__ __launch_bounds__(256) void ov_pert_slab_kernel(const float* __restri
         if (l0 + i < L) slab[(int64_t)(l0 + i) * ldb + b] = h[i];
 }
 
+// the term levels of this pass run as one launch per level (inference batch) and can write the activities themselves
+static bool ov_fm_fused(const OvStep& s) {
+    const ontovae_dims_t& d = s.c->dims;
+    if (s.ldb < OV_CHAIN_MAX_LDB && ov_fused_bt(s.c) != 0) return false;          // the chain kernel takes the term levels
+    if (s.vec != 4 || d.nu < 2 || d.nu > 4 || d.K > OV_MAX_LEVELS) return false;
+    for (int lvl = 1; lvl < d.K; ++lvl)
+        if ((s.c->level_end[lvl] - s.c->level_begin[lvl]) % d.nu != 0) return false;
+    return true;
+}
+
 extern "C" int ontovae_encode_pre(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, float* hpre, int64_t ldh,
                                   void* stream) {
     int rc = ov_check_ctx(ctx, B, false);
@@ -2522,8 +2629,11 @@ extern "C" int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float
     if ((rc = ov_reparam(s, eps1, 0, rng_offset, OV_RNG_EPS, 0, nullptr, true))) return rc;
     if (act_out && (rc = ov_act_out(s, 0, 1, act_out, act_ld, fm))) return rc;
     if ((rc = ov_reparam(s, eps2, 0, rng_offset, OV_RNG_EPS2, 0, nullptr, false))) return rc;
+    const bool fused = fm && act_out && ov_fm_fused(s);
+    if (fused) { s.fm_out = act_out; s.fm_ld = act_ld; }
     if ((rc = ov_dec_forward_terms(s, true))) return rc;
-    if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld, fm))) return rc;
+    s.fm_out = nullptr;
+    if (act_out && !fused && (rc = ov_act_out(s, 1, d.K, act_out, act_ld, fm))) return rc;
     if (rec_out && (rc = ov_dec_gene<2>(s, rec_out, rec_ld))) return rc;
     return ONTOVAE_OK;
 }

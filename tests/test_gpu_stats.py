@@ -283,3 +283,34 @@ def test_wilcox_test_dataframe_like_the_reference():
     res_g = dstats.wilcox_test(Onto(25), ctrl, pert, direction="down", option="genes", device=DEV)
     assert list(res_g.columns) == ["gene", "stat", "pval", "qval"] and len(res_g) == 25
     assert (np.diff(res_g["pval"].to_numpy()) >= 0).all()
+
+
+def test_perturbed_pass_feature_major_at_inference_batch():
+    """From 2048 columns on the term levels run one launch per level and, for a feature-major output, write the nu-means
+    themselves (one wave per term): against the sample-major output of the same pass, which takes the row-per-wave
+    kernel and the separate output kernel (same summation order; last-bit differences from fused multiply-adds)."""
+    model, onto, X, eps = _screen_model(N=2100, seed=5)
+    e = model._engine
+    N = X.shape[0]
+    model.eval()
+    Xd = torch.as_tensor(X, device=DEV)
+    hpre = torch.empty(e.plan.L, N, device=DEV)
+    e.encode_pre(Xd, None, hpre, 0)
+    genes, vals = [7, 300], [0.0, 2.5]
+    act = torch.empty(N, e.plan.T, device=DEV)
+    e.pass_data_perturbed(Xd, None, hpre, 0, genes, vals, eps[0], eps[1], act_out=act)
+    fm = torch.full((e.plan.T, N + 5), -7.0, device=DEV)
+    e.pass_data_perturbed(Xd, None, hpre, 0, genes, vals, eps[0], eps[1], act_fm=fm, act_fm_col0=2)
+    got, want = fm[:, 2:2 + N].t().cpu().numpy(), act.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max())
+    assert (fm[:, :2] == -7.0).all() and (fm[:, 2 + N:] == -7.0).all()
+    # and the screen built on it agrees with the full-pass recipe within what float32 rounding does to rank sums
+    names = model.genes
+    perts = [([names[7], names[300]], vals)]
+    out = {}
+    for rank1 in (False, True):
+        model.screen_rank1 = rank1
+        _replay(model, eps, N, model.inference_batch)
+        out[rank1] = model.perturbation_screen(onto, "d", perts, output="terms", direction="up")
+    total = N * (N + 1) / 2
+    assert np.abs(out[True]["stat"] - out[False]["stat"]).max() <= 0.002 * total
