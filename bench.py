@@ -160,6 +160,14 @@ def infer_bench(a, model, dev, world, rank):
         dist.destroy_process_group()
 
 
+def _pmc_traffic(key):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
 def screen_bench(a, model, dev, world, rank):
     """In-silico knock-out screen: a step is ONE single-gene perturbation of N resident samples:
     the perturbed pass from the cached first layer (ontovae_pass_data_perturbed), the move to feature-major, and the
@@ -251,8 +259,8 @@ def screen_bench(a, model, dev, world, rank):
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "full_pass_ms_per_step": dt_full / nfull * 1e3, "wilcoxon_kernel_ms": wx_ms},
             "roofline": {"bound": "hbm", "achieved": wx_bytes / (wx_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": wx_bytes / (wx_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                         "kernel": "ov_wilcoxon_sort_kernel (LDS bitonic sort: bound by LDS passes, not HBM)",
+                         "frac": wx_bytes / (wx_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _pmc_traffic("wilcoxon"),
+                         "kernel": "ov_wilcoxon_sort_kernel (bitonic sort in registers: bound by its vector instructions, not HBM)",
                          "algorithmic_bytes": wx_bytes}}))
     if world > 1:
         dist.destroy_process_group()
