@@ -314,3 +314,25 @@ def test_perturbed_pass_feature_major_at_inference_batch():
         out[rank1] = model.perturbation_screen(onto, "d", perts, output="terms", direction="up")
     total = N * (N + 1) / 2
     assert np.abs(out[True]["stat"] - out[False]["stat"]).max() <= 0.002 * total
+
+
+def test_screen_edge_cases():
+    """No perturbations, a dataset of one and of five samples (exact and enumeration branches of the test), a gene list of
+    exactly 64 and of 65 entries (rank-1 limit), repeated genes (the last value stays, as sequential overwriting gives)."""
+    model, onto, X, eps = _screen_model(N=5, seed=9)
+    T = model._engine.plan.T
+    names = model.genes
+    res = model.perturbation_screen(onto, "d", [])
+    assert res["stat"].shape == (0, T) and res["qval"].shape == (0, T)
+    many = [names[i] for i in range(65)]
+    _replay(model, eps, 5, model.inference_batch)
+    res = model.perturbation_screen(onto, "d", [(many[:64], [0.0] * 64), (many, [0.0] * 65), ([names[3], names[3]], [9.0, 0.0]), ([names[3]], [0.0])])
+    assert res["pval"].shape == (4, T) and np.isfinite(res["pval"]).all() and (res["qval"] <= 1).all()
+    assert ((res["stat"] >= 0) & (res["stat"] <= 15)).all()                      # n (n + 1) / 2 = 15
+    # a repeated gene keeps its last value: the same perturbation as listing it once, given the same eps draws
+    model.eps_source = lambda B: torch.as_tensor(eps[0, :B])
+    rep = model.perturbation_screen(onto, "d", [([names[3], names[3]], [9.0, 0.0]), ([names[3]], [0.0])])
+    np.testing.assert_array_equal(rep["stat"][0], rep["stat"][1])
+    onto.add_dataset("one", X[:1])
+    res1 = model.perturbation_screen(onto, "one", [([names[0]], [1.0])])
+    assert res1["pval"].shape == (1, T) and set(np.unique(res1["pval"])) <= {0.5, 1.0}
