@@ -275,6 +275,19 @@ int ontovae_dp_bn_bwd(const ontovae_ctx_t* ctx, int32_t B, int32_t B_global, con
 int ontovae_dw0_global(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, const int32_t* colmap,
                        int32_t n_ranks, int32_t blm, const float* gathered, int64_t rstride, const ontovae_adamw_t* opt,
                        int32_t apply_update, void* stream);
+/* The same with ONE exchange between the backward pass and dW0 instead of two (the all-reduce of the BatchNorm
+ * backward sums and the all-gather of dh): after phase 1 every rank packs what it has,
+ *   ontovae_dp_pack_dy: send = [L][blm] dy | [L] (b0 slot, zero) | [L][blm] xhat | [2 L] local (sum dy, sum dy xhat),
+ *     2 L blm + 3 L floats; columns >= B zero;
+ * the ranks all-gather these blocks (rank stride `rstride` floats, % 4 == 0), and
+ *   ontovae_dp_dh_global: adds the ranks' sums in rank order (the same bits on every rank), turns dy of ALL blocks into
+ *     dh in place, fills the b0 slots with the blocks' sums of dh, and writes the gradients of gamma and beta (the global
+ *     sums) to ctx->Gr.  sizes[r] (HOST array) = rows rank r really holds; their total must be B_global.
+ * ontovae_dw0_global then runs on the same buffer with the same `rstride`. */
+#define ONTOVAE_MAX_DP_RANKS 64
+int ontovae_dp_pack_dy(const ontovae_ctx_t* ctx, int32_t B, float* send, int32_t blm, void* stream);
+int ontovae_dp_dh_global(const ontovae_ctx_t* ctx, int32_t B_global, int32_t n_ranks, const int32_t* sizes,
+                         int32_t blm, float* gathered, int64_t rstride, void* stream);
 
 /* One body of OntoVAE.val_round (onto_vae/vae_model.py:204-209): eval-mode forward + vae_loss. */
 int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B,

@@ -2948,6 +2948,103 @@ extern "C" int ontovae_dp_bn_bwd(const ontovae_ctx_t* ctx, int32_t B, int32_t B_
     return ONTOVAE_OK;
 }
 
+// ---- one exchange instead of two between the backward pass and dW0 (data parallel) --------------------------------
+// After phase 1 a rank holds dy = dL/d(BatchNorm output) of its columns, xhat, and its local sums (sum dy, sum dy xhat).
+// Instead of all-reducing the sums and then all-gathering dh, the ranks all-gather [dy | . | xhat | sums] once; every
+// rank then forms the global sums (fixed rank order: bitwise the same everywhere) and dh of ALL columns itself.
+// Block of one rank, `rstride` floats: [L][blm] dy -> dh in place | [L] b0 gradient of the block | [L][blm] xhat | [2 L] sums.
+__global__ __launch_bounds__(256) void ov_dp_pack_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                        const float* __restrict__ sums, int L, int B, int ldb, int blm,
+                                                        float* __restrict__ send) {
+    const int l = blockIdx.x;
+    float* d0 = send + (int64_t)l * blm;
+    float* x0 = send + (int64_t)L * blm + L + (int64_t)l * blm;
+    for (int b = threadIdx.x; b < blm; b += 256) {
+        d0[b] = b < B ? dy[(int64_t)l * ldb + b] : 0.f;
+        x0[b] = b < B ? xhat[(int64_t)l * ldb + b] : 0.f;
+    }
+    if (threadIdx.x == 0) {
+        send[(int64_t)L * blm + l] = 0.f;
+        send[(int64_t)2 * L * blm + L + l] = sums[l];
+        send[(int64_t)2 * L * blm + 2 * L + l] = sums[L + l];
+    }
+}
+
+struct OvDpSizes { int n[ONTOVAE_MAX_DP_RANKS]; };
+__global__ __launch_bounds__(256) void ov_dp_dh_kernel(float* __restrict__ gathered, int64_t rstride, int R, const OvDpSizes sz, int L,
+                                                      int blm, int Bglobal, const float* __restrict__ gamma,
+                                                      const float* __restrict__ invstd, float* __restrict__ G_gamma,
+                                                      float* __restrict__ G_beta) {
+    // one wave per feature, as ov_bn_bwd_body
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (l >= L) return;
+    float gdy = 0.f, gdyx = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float* sums = gathered + r * rstride + (int64_t)2 * L * blm + L;
+        gdy += sums[l];
+        gdyx += sums[L + l];
+    }
+    const float nb = (float)Bglobal;
+    const float scale = gamma[l] * invstd[l] / nb;
+    for (int r = 0; r < R; ++r) {
+        float* blk = gathered + r * rstride;
+        float* dyr = blk + (int64_t)l * blm;
+        const float* xr = blk + (int64_t)L * blm + L + (int64_t)l * blm;
+        float sdh = 0.f;
+        for (int b = lane; b < blm; b += 64) {
+            float v = 0.f;
+            if (b < sz.n[r]) {
+                v = scale * (nb * dyr[b] - gdy - xr[b] * gdyx);
+                sdh += v;
+            }
+            dyr[b] = v;
+        }
+        sdh = ov_wave_sum(sdh);
+        if (lane == 0) blk[(int64_t)L * blm + l] = sdh;
+    }
+    if (lane == 0) { G_gamma[l] = gdyx; G_beta[l] = gdy; }
+}
+
+extern "C" int ontovae_dp_pack_dy(const ontovae_ctx_t* ctx, int32_t B, float* send, int32_t blm, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!send) { ontovae_set_error("dp_pack_dy: send is NULL"); return ONTOVAE_EINVAL; }
+    if (blm < B || (blm & 3)) { ontovae_set_error("dp_pack_dy: blm %d must be a multiple of 4 and >= B = %d", blm, B); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, nullptr, nullptr, B, stream, &s);
+    const ontovae_dims_t& d = ctx->dims;
+    hipLaunchKernelGGL(ov_dp_pack_kernel, dim3(d.L), dim3(256), 0, s.st, s.ws.dh, s.ws.xhat, s.ws.bn_bwd_local, d.L, B, s.ldb, blm, send);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_dp_dh_global(const ontovae_ctx_t* ctx, int32_t B_global, int32_t n_ranks, const int32_t* sizes, int32_t blm,
+                                    float* gathered, int64_t rstride, void* stream) {
+    if (!ctx || !gathered || !sizes || !ctx->Gr || !ctx->workspace) { ontovae_set_error("dp_dh_global: a required pointer is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_dims_t& d = ctx->dims;
+    if (n_ranks < 1 || n_ranks > ONTOVAE_MAX_DP_RANKS || blm < 4 || (blm & 3) || rstride < (int64_t)2 * d.L * blm + 3 * d.L) {
+        ontovae_set_error("dp_dh_global: n_ranks = %d (at most %d), blm = %d, rstride = %lld", n_ranks, ONTOVAE_MAX_DP_RANKS, blm, (long long)rstride);
+        return ONTOVAE_EINVAL;
+    }
+    OvDpSizes sz{};
+    int total = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        if (sizes[r] < 0 || sizes[r] > blm) { ontovae_set_error("dp_dh_global: rank %d holds %d rows, blm = %d", r, sizes[r], blm); return ONTOVAE_EINVAL; }
+        sz.n[r] = sizes[r];
+        total += sizes[r];
+    }
+    if (total != B_global) { ontovae_set_error("dp_dh_global: the ranks hold %d rows, B_global = %d", total, B_global); return ONTOVAE_EINVAL; }
+    OvWs ws;
+    ov_carve(d, ctx->max_batch, ctx->workspace, &ws);
+    const ontovae_layout_t& lay = ctx->lay;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    OvProfScope prof(ONTOVAE_PHASE_BN_BWD, st);
+    hipLaunchKernelGGL(ov_dp_dh_kernel, dim3((d.L + 3) / 4), dim3(256), 0, st, gathered, rstride, n_ranks, sz, d.L, blm, B_global,
+                       ctx->P + lay.gamma, ws.bn_invstd, ctx->Gr + lay.gamma, ctx->Gr + lay.beta);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
 extern "C" int ontovae_dw0_global(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, const int32_t* colmap,
                                   int32_t n_ranks, int32_t blm, const float* gathered, int64_t rstride,
                                   const ontovae_adamw_t* opt, int32_t apply_update, void* stream) {

@@ -301,6 +301,18 @@ class Engine:
         _lib.check(_lib.lib().ontovae_dp_bn_bwd(C.byref(ctx), int(B), int(B_global), _ptr(bn_bwd_stats), offset, _ptr(send),
                                                 int(blm), self.stream()), "dp_bn_bwd")
 
+    def dp_pack_dy(self, B, send, blm):
+        """After DP phase 1: this rank's block [dy | b0 slot | xhat | local sums] for the single all-gather."""
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_dp_pack_dy(C.byref(ctx), int(B), _ptr(send), int(blm), self.stream()), "dp_pack_dy")
+
+    def dp_dh_global(self, B_global, sizes, blm, gathered, rstride):
+        """Global BatchNorm-backward sums and dh of every rank's columns from the all-gathered blocks, in place."""
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+        ctx = self.ctx(max(self.max_batch, 1))
+        _lib.check(_lib.lib().ontovae_dp_dh_global(C.byref(ctx), int(B_global), len(sizes), sizes.ctypes.data_as(_lib.c_i32p), int(blm),
+                                                   _ptr(gathered), int(rstride), self.stream()), "dp_dh_global")
+
     def dw0_global(self, x, xidx, colmap, n_ranks, blm, gathered, rstride, adam):
         """dW0 of the global batch from the all-gathered dh blocks (+ the b0 gradient: sum of the blocks' b0 parts);
         adam=None stores the gradient in Gr."""

@@ -4,10 +4,11 @@ row 12); the contract is that an R-rank step equals the single-device step on th
 
   * every rank sees the same global batch order and takes rows shard_bounds(B, R, r) of it;
   * SyncBN forward: all-gather of per-rank (mean, M2, n), combined with Chan's formula;
-  * SyncBN backward: all-reduce SUM of (sum dy, sum dy*xhat);
-  * gradients: all-reduce SUM (the loss is a SUM over the batch, reference vae_model.py:124-129),
-    in two buckets of the flat gradient buffer: [heads | decoder] is complete after phase 1 and
-    its all-reduce overlaps the dW0 GEMM of phase 2; [W0 | b0 | gamma | beta] follows.
+  * SyncBN backward + first layer: ONE all-gather of [dy | xhat | (sum dy, sum dy*xhat)] per rank; every rank adds
+    the sums in rank order, forms dh of all columns and dW0 = dh x of the global batch itself (small global batches),
+    or: all-reduce SUM of the sums, then all-reduce of the first layer's gradient (large global batches);
+  * the other gradients: all-reduce SUM (the loss is a SUM over the batch, reference vae_model.py:124-129) of the
+    [heads | decoder] part of the flat gradient buffer, complete after phase 1, under the dW0 kernel.
 
 No collective is on the inference path: samples are independent, ranks take disjoint slices.
 """
@@ -69,6 +70,11 @@ class _DpState:
             m += [starts[r] + j if j < sizes[r] else starts[r] for j in range(self.blm)]
         self.colmap = torch.tensor(m, dtype=torch.int64, device=dev)
         self.colmap32 = self.colmap.to(torch.int32)
+        # one exchange instead of two (ontovae_dp_pack_dy / ontovae_dp_dh_global): per rank [L][blm] dy | [L] | [L][blm] xhat | [2 L]
+        self.sizes = sizes
+        self.rstride2 = (2 * L * self.blm + 3 * L + 3) // 4 * 4
+        self.send2 = torch.zeros(self.rstride2, device=dev)
+        self.gathered2 = torch.zeros(world * self.rstride2, device=dev)
 
 
 def _dp_state(e, B, world, rank):
@@ -107,8 +113,9 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
     given, is the global [B, L] draw.  Exchanges: SyncBN forward (all-gather of 2L+1 floats per rank, combined inside
     the BatchNorm kernel), SyncBN backward (all-reduce of 2L floats), gradients of the heads and the decoder
     (all-reduce, 3 MB at GO-BP scale, under the dW0 kernel), and for the first layer either
-      * dh [L, B_local] (all-gather): dW0 = dh x of the GLOBAL batch is then formed, and applied, by every rank itself
-        (ontovae_dw0_global), so the 28.8 MB gradient never crosses the links; or
+      * an all-gather of [dy | xhat | local sums] (which also replaces the SyncBN-backward all-reduce): every rank
+        then forms dh of all columns and dW0 = dh x of the GLOBAL batch itself, and applies it (ontovae_dp_dh_global,
+        ontovae_dw0_global), so the 28.8 MB gradient never crosses the links; or
       * the all-reduce of that gradient followed by the flat AdamW pass,
     whichever use_gathered_dh estimates to be shorter (small global batches: the first; large ones: the second).
     reduce_loss=False leaves this rank's partial sums in loss_out (the caller all-reduces a whole epoch at once)."""
@@ -132,22 +139,33 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
     dist.all_gather_into_tensor(st.stats_all, st.stats_send, group=group)
 
     e.train_step_dp(16 + world, xl, il, B, el, kl_coeff, st.stats_all, st.bstats, lbuf, off)
-    dist.all_reduce(st.bstats, group=group)
 
     hyper = opt.next_hyper()
     if use_gathered_dh(B, world, L, e.plan.G):
-        e.dp_bn_bwd(size, B, st.bstats, off, st.send, st.blm)
-        dist.all_gather_into_tensor(st.gathered, st.send, group=group)
+        if os.environ.get("ONTOVAE_DP_TWO_EXCHANGES") == "1":
+            # all-reduce of the BatchNorm-backward sums, then all-gather of dh
+            dist.all_reduce(st.bstats, group=group)
+            e.dp_bn_bwd(size, B, st.bstats, off, st.send, st.blm)
+            dist.all_gather_into_tensor(st.gathered, st.send, group=group)
+            gathered, rstride = st.gathered, st.rstride
+        else:
+            # one exchange: all-gather of [dy | xhat | local sums]; every rank adds the sums in rank order and forms dh of
+            # all columns itself (one small collective less on the critical path)
+            e.dp_pack_dy(size, st.send2, st.blm)
+            dist.all_gather_into_tensor(st.gathered2, st.send2, group=group)
+            e.dp_dh_global(B, st.sizes, st.blm, st.gathered2, st.rstride2)
+            gathered, rstride = st.gathered2, st.rstride2
         # issued after the all-gather (collectives of one communicator run in order, and dW0 waits for the gather
         # only); it then runs under the dW0 kernel
         h_early = dist.all_reduce(e.Gr[int(lay.Wh):int(lay.total)], group=group, async_op=True)
         if xidx is None:
-            e.dw0_global(e._x(x, None)[0], None, st.colmap32, world, st.blm, st.gathered, st.rstride, hyper)
+            e.dw0_global(e._x(x, None)[0], None, st.colmap32, world, st.blm, gathered, rstride, hyper)
         else:
-            e.dw0_global(x, xidx, st.colmap32, world, st.blm, st.gathered, st.rstride, hyper)
+            e.dw0_global(x, xidx, st.colmap32, world, st.blm, gathered, rstride, hyper)
         h_early.wait()
         e.adamw_apply_range(hyper, int(lay.b0), int(lay.total))
     else:
+        dist.all_reduce(st.bstats, group=group)
         late, early = grad_buckets(lay)
         h_early = dist.all_reduce(e.Gr[early[0]:early[1]], group=group, async_op=True)     # under the dW0 GEMM
         e.train_step_dp(2, xl, il, B, el, kl_coeff, st.stats, st.bstats, lbuf, off)

@@ -332,8 +332,9 @@ def test_dp_phases_equal_fused_step():
     assert torch.equal(ranks[0]._engine.P, ranks[1]._engine.P)
 
 
+@pytest.mark.parametrize("one_exchange", [False, True])
 @pytest.mark.parametrize("parts", [[(0, 40), (40, 96)], [(0, 70), (70, 140), (140, 209)], [(128 * r, 128 * r + 128) for r in range(8)]])
-def test_dp_gathered_dh_equals_fused_step(parts):
+def test_dp_gathered_dh_equals_fused_step(parts, one_exchange):
     """The data-parallel step without an all-reduce of dW0: simulated ranks on one GPU, collectives by hand.  Every
     rank forms dW0 of the GLOBAL batch from the all-gathered dh blocks (ontovae_dp_bn_bwd, ontovae_dw0_global; global
     batch 96 = one chunk, 209 = two chunks of the K loop) and must land on the single-device step's parameters."""
@@ -381,14 +382,26 @@ def test_dp_gathered_dh_equals_fused_step(parts):
     lay = ranks[0]._engine.plan.layout
     early = slice(int(lay.Wh), int(lay.total))
     gearly = sum(m._engine.Gr[early] for m in ranks)
-    for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
-        m._engine.dp_bn_bwd(b - a, B, bsum, 1, sts[r].send, sts[r].blm)
-    gathered = torch.cat([st.send for st in sts])
+    if one_exchange:        # all-gather of [dy | xhat | local sums]; sums and dh of all columns formed by every rank itself
+        blm = sts[0].blm
+        rstride = (2 * L * blm + 3 * L + 3) // 4 * 4
+        sends = []
+        for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+            sends.append(torch.full((rstride,), 7.0, device="cuda"))
+            m._engine.dp_pack_dy(b - a, sends[-1], blm)
+        gathered = torch.cat(sends)
+    else:
+        for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+            m._engine.dp_bn_bwd(b - a, B, bsum, 1, sts[r].send, sts[r].blm)
+        gathered, rstride = torch.cat([st.send for st in sts]), sts[0].rstride
     for m in ranks:
         e = m._engine
         e.Gr[early].copy_(gearly)
         hyper = FusedAdamW(m, lr=lr).next_hyper()
-        e.dw0_global(x, None, colmap, R, sts[0].blm, gathered, sts[0].rstride, hyper)      # also sums the b0 parts into Gr
+        g = gathered.clone()
+        if one_exchange:
+            e.dp_dh_global(B, [b - a for a, b in parts], sts[0].blm, g, rstride)
+        e.dw0_global(x, None, colmap, R, sts[0].blm, g, rstride, hyper)      # also sums the b0 parts into Gr
         e.adamw_apply_range(hyper, int(lay.b0), int(lay.total))
     lsum = sum(louts)
     np.testing.assert_allclose(lsum[:2].cpu().numpy(), rout[:2].cpu().numpy(), rtol=1e-5)
@@ -397,7 +410,7 @@ def test_dp_gathered_dh_equals_fused_step(parts):
         assert torch.equal(ranks[0]._engine.P, m._engine.P)          # replicas stay bitwise identical
 
 
-@pytest.mark.parametrize("use_idx,allreduce", [(1, 0), (0, 0), (1, 1)])
+@pytest.mark.parametrize("use_idx,allreduce", [(1, 0), (0, 0), (1, 1), (1, 2)])
 def test_dp_two_processes_one_gpu(tmp_path, use_idx, allreduce):
     """onto_vae_amd.parallel.dp_train_step end to end, collectives included: two worker processes share GPU 0 and talk
     through gloo; three steps on a global batch of 100 rows must land where the single-process steps land, and the
@@ -422,7 +435,9 @@ def test_dp_two_processes_one_gpu(tmp_path, use_idx, allreduce):
         ref._engine.train_step(Xd, torch.as_tensor(idx[s * B:(s + 1) * B]).cuda(), torch.as_tensor(eps[s]), 1e-4,
                                ropt.next_hyper(), rl[s])
     port = str(29600 + (os.getpid() % 300))
-    env = dict(os.environ, ONTOVAE_DP_ALLREDUCE=str(allreduce))
+    # 0: all-gather of [dy | xhat | sums] (default), 1: all-reduce of the first layer's gradient, 2: the two-exchange form
+    # of 0 (all-reduce of the BatchNorm-backward sums, then all-gather of dh)
+    env = dict(os.environ, ONTOVAE_DP_ALLREDUCE=str(min(allreduce, 1) if allreduce < 2 else 0), ONTOVAE_DP_TWO_EXCHANGES="1" if allreduce == 2 else "0")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, path, str(steps)], env=env) for r in range(2)]
     for p in procs:
