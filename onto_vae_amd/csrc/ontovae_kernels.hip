@@ -2510,6 +2510,7 @@ static int ov_act_out(OvStep& s, int lvl_from, int lvl_to, float* act_out, int64
     return ONTOVAE_OK;
 }
 
+static bool ov_fm_fused(const OvStep& s);
 extern "C" int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps1,
                                  const float* eps2, uint64_t rng_offset, float* act_out, int64_t act_ld, float* rec_out,
                                  int64_t rec_ld, void* stream) {
@@ -2523,10 +2524,19 @@ extern "C" int ontovae_pass_data(const ontovae_ctx_t* ctx, const float* x, const
     // The reference runs the encoder twice (get_embedding, then forward); in eval mode both runs give
     // the same mu / log_var, so one encoder pass and two reparameterisations are identical.
     if ((rc = ov_encode(s, eps1, 0, rng_offset, OV_RNG_EPS, 0, nullptr))) return rc;
-    if (act_out && (rc = ov_act_out(s, 0, 1, act_out, act_ld))) return rc;          // z part from draw #1
+    // Inference batches: the level launches write the nu-means themselves, feature-major, into the (idle) D panel of the
+    // workspace, and one transposition brings all T columns to the caller's sample-major matrix; otherwise the output
+    // kernel reads the finished panel.
+    const bool fused = act_out && ov_fm_fused(s);
+    float* fm = s.ws.d;
+    if (act_out && (rc = fused ? ov_act_out(s, 0, 1, fm, s.ldb, true) : ov_act_out(s, 0, 1, act_out, act_ld))) return rc;   // z part from draw #1
     if ((rc = ov_reparam(s, eps2, 0, rng_offset, OV_RNG_EPS2, 0, nullptr, false))) return rc;  // draw #2 feeds the decoder
+    if (fused) { s.fm_out = fm; s.fm_ld = s.ldb; }
     if ((rc = ov_dec_forward_terms(s, true))) return rc;
-    if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld))) return rc;
+    s.fm_out = nullptr;
+    if (fused) {
+        if ((rc = ov_transpose_out(s, fm, d.T, act_out, act_ld))) return rc;
+    } else if (act_out && (rc = ov_act_out(s, 1, d.K, act_out, act_ld))) return rc;
     if (rec_out && (rc = ov_dec_gene<2>(s, rec_out, rec_ld))) return rc;
     return ONTOVAE_OK;
 }
