@@ -449,7 +449,9 @@ __global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mul
     const int64_t n = (int64_t)L * ldb;
     float kl = 0.f;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)nrep * 256) {
-        const int l = (int)(idx / ldb), b = (int)(idx % ldb);
+        // ldb is a multiple of 64: the split into (feature, column) needs no 64-bit division
+        const uint32_t q = (uint32_t)(idx >> 6) / (uint32_t)(ldb >> 6);
+        const int l = (int)q, b = (int)(idx - (int64_t)q * ldb);
         float z = 0.f, e = 0.f;
         if (b < B) {
             float mu, lv;
@@ -2179,7 +2181,8 @@ static int ov_reparam(OvStep& s, const float* eps, int train, uint64_t rng_off, 
     OvRefresh rf{};
     const int rblocks = with_refresh ? ov_refresh_args(c, &rf) : 0;
     OvProfScope prof(ONTOVAE_PHASE_REPARAM, s.st);
-    hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks + rblocks), dim3(256), 0, s.st, s.ws.mulv, eps, s.ws.epsw, zrows, s.ws.kl_part,
+    // eps is kept for the backward pass only
+    hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks + rblocks), dim3(256), 0, s.st, s.ws.mulv, eps, train ? s.ws.epsw : nullptr, zrows, s.ws.kl_part,
                        d.L, s.B, s.ldb, train, c->z_drop, c->seed, rng_off, eps_stream, write_kl, blocks, rf,
                        s.heads_S > 0 ? s.ws.slab : (const float*)nullptr, s.heads_S, (int64_t)2 * d.L * s.ldb, c->P + c->lay.bh);
     OV_LAUNCH_CHECK();
