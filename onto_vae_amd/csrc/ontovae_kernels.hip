@@ -1793,6 +1793,28 @@ __global__ __launch_bounds__(256) void ov_transpose_out_kernel(const float* __re
     }
 }
 
+// the same in 64 x 64 tiles (whole 256-byte rows per wave on both sides), for inference batches
+__global__ __launch_bounds__(256) void ov_transpose_out64_kernel(const float* __restrict__ src, int F, int B, int ldb,
+                                                                float* __restrict__ dst, int64_t ld_out) {
+    __shared__ float tile[64][65];
+    const int f0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int f = f0 + ty + 4 * q, b = b0 + tx;
+        v[q] = (f < F && b < B) ? src[(int64_t)f * ldb + b] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[ty + 4 * q][tx] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int b = b0 + ty + 4 * q, f = f0 + tx;
+        if (f < F && b < B) dst[(int64_t)b * ld_out + f] = tile[tx][ty + 4 * q];
+    }
+}
+
 // sample-major z [B, L] -> feature-major panel rows
 __global__ __launch_bounds__(256) void ov_transpose_in_kernel(const float* __restrict__ src, int F, int B, int ldb,
                                                              float* __restrict__ dst) {
@@ -2433,6 +2455,11 @@ static int ov_encode(OvStep& s, const float* eps, int train, uint64_t rng_off, u
 }
 
 static int ov_transpose_out(OvStep& s, const float* src, int F, float* dst, int64_t ld) {
+    if (s.B >= 1024 && F >= 64) {
+        hipLaunchKernelGGL(ov_transpose_out64_kernel, dim3((F + 63) / 64, (s.B + 63) / 64), dim3(256), 0, s.st, src, F, s.B, s.ldb, dst, ld);
+        OV_LAUNCH_CHECK();
+        return ONTOVAE_OK;
+    }
     dim3 grid((F + 31) / 32, (s.B + 31) / 32);
     hipLaunchKernelGGL(ov_transpose_out_kernel, grid, dim3(256), 0, s.st, src, F, s.B, s.ldb, dst, ld);
     OV_LAUNCH_CHECK();
