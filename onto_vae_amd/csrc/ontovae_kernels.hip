@@ -127,6 +127,8 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs
     int64_t slab = 0;
     for (int b = 64; b <= ldb; b += 64)
         slab = std::max<int64_t>(slab, (int64_t)ov_enc_splitk(d.L, b, d.G) * L * ov_ldb(b));
+    // the heads GEMM leaves its [2L, ldb] output (1 to 3 split-K slabs) in the same buffer (ov_heads_fwd)
+    slab = std::max<int64_t>(slab, 2 * L * ldb);
     const int64_t npart = ((G + 3) / 4) * (ldb / 64) + 1024;
     int64_t off = 0;
     auto take = [&](int64_t n) {
@@ -2165,6 +2167,10 @@ static int ov_heads_fwd(OvStep& s) {
     g.B = s.ws.a; g.ldb = s.ldb; g.bgather = nullptr;
     // split-K partials into the (now free) encoder slab buffer; ov_reparam adds them and the bias
     const int64_t one = (int64_t)2 * d.L * s.ldb;
+    if (s.ws.slab_floats < one) {
+        ontovae_set_error("heads GEMM: slab buffer holds %lld floats, [2L, ldb] needs %lld", (long long)s.ws.slab_floats, (long long)one);
+        return ONTOVAE_EINVAL;
+    }
     const int S = s.ldb >= 1024 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(3, s.ws.slab_floats / one));
     int kchunk = ((d.L + S - 1) / S + 31) / 32 * 32;
     g.C = s.ws.slab; g.ldc = s.ldb; g.slab_stride = one; g.kchunk = kchunk;

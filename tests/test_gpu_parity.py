@@ -267,6 +267,36 @@ def test_large_panels_two_and_one_columns_per_workgroup(counts, nu):
     assert np.abs(e.view("Wmu", G_).cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("B", [100, 128, 1100])
+def test_small_gene_count_heads_output_fits_workspace(B):
+    """G < 512: the encoder GEMM takes no split-K, so its slab used to be [L, ldb] only while the heads GEMM writes
+    [2L, ldb] into the same buffer (log_var rows ran into xhat, which the BatchNorm backward reads).  Gradients of every
+    encoder tensor against the oracle at batch sizes with ldb == ldb(max_batch)."""
+    from ontovae_oracle import OracleOntoVAE
+    from onto_vae_amd.synthetic import synthetic_masks, random_state_dict
+    G, nu = 200, 3
+    masks = synthetic_masks([20, 30, 25], G, 31)
+    sd = random_state_dict(masks, nu, 32)
+    rng = np.random.RandomState(33 + B)
+    x = np.log1p(rng.poisson(0.5, size=(B, G))).astype(np.float32)
+    eps = rng.standard_normal((B, 20 * nu)).astype(np.float32)
+    o = OracleOntoVAE(masks, nu)
+    o.load_state_dict(sd)
+    rec, kl, loss, g = o.gradients(x, eps, 1e-4)
+    model, _ = make_model(masks, nu, sd)
+    e = model._engine
+    out = torch.zeros(3, device="cuda")
+    e.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), 1e-4, None, out, apply_update=False)
+    assert e.max_batch == max(B, 128)
+    np.testing.assert_allclose(out.cpu().numpy(), [rec, kl, loss], rtol=REL)
+    Gr = e.Gr
+    got = {"encoder.encoder.0.0.weight": e.view("W0", Gr), "encoder.encoder.0.1.weight": e.view("gamma", Gr),
+           "encoder.encoder.0.1.bias": e.view("beta", Gr), "encoder.mu.0.weight": e.view("Wmu", Gr),
+           "encoder.logvar.0.weight": e.view("Wlv", Gr), "encoder.logvar.0.bias": e.view("blv", Gr)}
+    for k, v in got.items():
+        assert np.abs(v.cpu().numpy() - g[k]).max() <= 2e-5 * np.abs(g[k]).max(), k
+
+
 def test_row_gather_equals_plain_batch():
     """(dataset, row indices) addressing gives the same step as a gathered batch."""
     from onto_vae_amd.vae_model import FusedAdamW
