@@ -373,6 +373,13 @@ int ontovae_wilcoxon_zsplit(const float* perturbed, const float* control, int64_
 int64_t ontovae_fdr_workspace_bytes(int32_t n, int32_t nsets);
 int ontovae_fdr_bh(const double* pvals, int32_t n, int32_t nsets, double* qvals, void* workspace,
                    int64_t workspace_bytes, void* stream);
+/* ontovae_fdr_bh without a workspace and without any allocation.  No counterpart in the reference: it is for callers
+ * that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  The `raw` values and NaN flags that ontovae_fdr_bh keeps in the caller's workspace live in a file-scope
+ * device array of the library instead (2 MiB + 16 KiB per GPU, held until the process ends).  Limits: n * nsets <= 262144
+ * p-values and nsets <= 4096; larger inputs return ONTOVAE_EINVAL (use ontovae_fdr_bh).  Results are bit-identical to
+ * ontovae_fdr_bh.  All calls on one GPU share the array: calls that overlap on one GPU (two streams) race. */
+int ontovae_fdr_bh_static(const double* pvals, int32_t n, int32_t nsets, double* qvals, void* stream);
 int ontovae_to_feature_major(const float* src, int64_t src_ld, int32_t B, int32_t F, float* dst,
                              int64_t dst_ld, void* stream);
 

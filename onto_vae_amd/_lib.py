@@ -108,6 +108,7 @@ def lib():
         "ontovae_dense_to_vals": [vp, i64, vp, vp, i64, i64, vp, vp],
         "ontovae_wilcoxon_zsplit": [vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp],
         "ontovae_fdr_bh": [vp, i32, i32, vp, vp, i64, vp],
+        "ontovae_fdr_bh_static": [vp, i32, i32, vp, vp],
         "ontovae_to_feature_major": [vp, i64, i32, i32, vp, i64, vp],
         "ontovae_profile_begin": [C.c_uint32, i32],
         "ontovae_profile_read": [i32, c_f32p, i32, c_i32p],
@@ -135,7 +136,7 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_adamw_apply", "ontovae_adamw_apply_range", "ontovae_dp_bn_bwd", "ontovae_dw0_global", "ontovae_dp_pack_dy", "ontovae_dp_dh_global", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
             "ontovae_encode_pre", "ontovae_pass_data_perturbed",
             "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals",
-            "ontovae_wilcoxon_workspace_bytes", "ontovae_wilcoxon_zsplit", "ontovae_fdr_workspace_bytes", "ontovae_fdr_bh",
+            "ontovae_wilcoxon_workspace_bytes", "ontovae_wilcoxon_zsplit", "ontovae_fdr_workspace_bytes", "ontovae_fdr_bh", "ontovae_fdr_bh_static",
             "ontovae_to_feature_major",
             "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end"]
 

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include "ontovae_internal.h"
 
@@ -596,6 +597,63 @@ extern "C" int ontovae_fdr_bh(const double* pvals, int32_t n, int32_t nsets, dou
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     double* raw = reinterpret_cast<double*>(workspace);
     int* nanflag = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + ((int64_t)n * nsets * 8 + 255) / 256 * 256);
+    OV_HIP_CHECK(hipMemsetAsync(nanflag, 0, sizeof(int) * nsets, st));
+    const dim3 grid((n + 255) / 256, nsets);
+    hipLaunchKernelGGL(ov_fdr_raw_kernel, grid, dim3(256), 0, st, pvals, n, raw, nanflag);
+    OV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ov_fdr_min_kernel, grid, dim3(256), 0, st, pvals, raw, n, nanflag, qvals);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ontovae_fdr_bh for callers that cannot allocate (HIP graph capture, serving loops): the `raw` values and the NaN flags
+// live in a file-scope device array instead of a caller workspace.  Every GPU the library runs on holds its own copy of
+// the array (2 MiB + 16 KiB) until the process ends; its device address is looked up once per device, with that device
+// current, and only that pointer is ever handed to kernels or memsets (the array's name is a host-side stand-in).
+// Calls on one GPU share the array: two of them in flight at once (different streams) race.
+// ---------------------------------------------------------------------------------------------------------------------
+#define OV_FDR_STATIC_PVALS (1 << 18)          // n * nsets at most
+#define OV_FDR_STATIC_SETS 4096                // nsets at most
+#define OV_FDR_STATIC_RAW_BYTES ((size_t)OV_FDR_STATIC_PVALS * sizeof(double))
+#define OV_FDR_STATIC_BYTES (OV_FDR_STATIC_RAW_BYTES + (size_t)OV_FDR_STATIC_SETS * sizeof(int))
+static __device__ __align__(256) unsigned char ov_fdr_scratch[OV_FDR_STATIC_BYTES];
+
+#define OV_MAX_DEVICES 64
+static std::mutex g_fdr_scratch_mutex;
+static void* g_fdr_scratch_ptr[OV_MAX_DEVICES] = {nullptr};
+
+// device address of this device's copy of ov_fdr_scratch (the current device), looked up on the first call per device
+static int ov_fdr_scratch_get(void** out) {
+    int dev = -1;
+    OV_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= OV_MAX_DEVICES) { ontovae_set_error("fdr_bh_static: device index %d out of range", dev); return ONTOVAE_EINVAL; }
+    std::lock_guard<std::mutex> lock(g_fdr_scratch_mutex);
+    if (!g_fdr_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        OV_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(ov_fdr_scratch)));
+        if (!ptr || (reinterpret_cast<uintptr_t>(ptr) & 255)) { ontovae_set_error("fdr_bh_static: bad scratch address %p", ptr); return ONTOVAE_EHIP; }
+        g_fdr_scratch_ptr[dev] = ptr;
+    }
+    *out = g_fdr_scratch_ptr[dev];
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_fdr_bh_static(const double* pvals, int32_t n, int32_t nsets, double* qvals, void* stream) {
+    if (n < 0 || nsets < 0) { ontovae_set_error("fdr_bh_static: n = %d, nsets = %d", n, nsets); return ONTOVAE_EINVAL; }
+    if (n == 0 || nsets == 0) return ONTOVAE_OK;
+    if (!pvals || !qvals) { ontovae_set_error("fdr_bh_static: NULL argument"); return ONTOVAE_EINVAL; }
+    if ((int64_t)n * nsets > OV_FDR_STATIC_PVALS || nsets > OV_FDR_STATIC_SETS) {
+        ontovae_set_error("fdr_bh_static: %d sets of %d p-values exceed the static scratch (n * nsets <= %d, nsets <= %d); "
+                          "use ontovae_fdr_bh with a workspace", nsets, n, OV_FDR_STATIC_PVALS, OV_FDR_STATIC_SETS);
+        return ONTOVAE_EINVAL;
+    }
+    void* base = nullptr;
+    { const int rc = ov_fdr_scratch_get(&base); if (rc) return rc; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    double* raw = reinterpret_cast<double*>(base);
+    int* nanflag = reinterpret_cast<int*>(reinterpret_cast<char*>(base) + OV_FDR_STATIC_RAW_BYTES);
+    // the array keeps the previous call's contents: the flags must start at zero, raw is fully rewritten for [0, n * nsets)
     OV_HIP_CHECK(hipMemsetAsync(nanflag, 0, sizeof(int) * nsets, st));
     const dim3 grid((n + 255) / 256, nsets);
     hipLaunchKernelGGL(ov_fdr_raw_kernel, grid, dim3(256), 0, st, pvals, n, raw, nanflag);
