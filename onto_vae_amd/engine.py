@@ -5,6 +5,7 @@ the ontovae_ctx_t that every C entry point takes.  torch is plumbing here: it al
 provides the stream and (for data parallel) the collectives.
 """
 import ctypes as C
+import functools
 import math
 
 import numpy as np
@@ -22,6 +23,18 @@ def norm_device(device):
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     return device
+
+
+def _on_device(fn):
+    """Run an entry point with the engine's GPU as the current HIP device: the library keys its per-device state (LDS
+    attributes, side stream) on hipGetDevice(), and a launch into another device's stream fails."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        if self.device.type != "cuda" or torch.cuda.current_device() == self.device.index:
+            return fn(self, *a, **k)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
 
 
 def _ptr(t):
@@ -88,10 +101,20 @@ class Engine:
         cout, cin = self.plan.layer_shapes[i]
         k0, k1 = self.plan.layer_entries[i]
         dense = torch.zeros(cout, cin, dtype=torch.float32, device=self.device)
-        if k1 > k0:
+        if k1 > k0 and self.device.type != "cuda":      # state_dict export without the GPU (host plumbing only)
             er, ec = self._entry_rc()
             dense[er[k0:k1].long(), ec[k0:k1].long()] = self.layer_vals(i, buf)
+        elif k1 > k0:
+            self._scatter_vals(self.view("dec_vals", buf), k0, k1, dense)
         return dense
+
+    def _scatter_vals(self, vals, k0, k1, dense):
+        """dense[row, col of entry k] = vals[k], k in [k0, k1) (ontovae_vals_to_dense)."""
+        self._require_gpu()
+        er, ec = self._entry_rc()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ontovae_vals_to_dense(_ptr(vals), _ptr(er), _ptr(ec), int(k0), int(k1), _ptr(dense), dense.stride(0),
+                                                        self.stream()), "vals_to_dense")
 
     def set_layer_dense(self, i, dense, buf=None):
         """Import a dense weight; returns the largest |value| found off the mask (dropped)."""
@@ -99,14 +122,24 @@ class Engine:
         dense = torch.as_tensor(dense, dtype=torch.float32, device=self.device)
         if tuple(dense.shape) != (cout, cin):
             raise ValueError(f"decoder layer {i}: expected shape {(cout, cin)}, got {tuple(dense.shape)}")
+        dense = dense.contiguous()
         k0, k1 = self.plan.layer_entries[i]
+        if self.device.type != "cuda":      # a model can be constructed, loaded and saved without the GPU
+            er, ec = self._entry_rc()
+            r, c = er[k0:k1].long(), ec[k0:k1].long()
+            self.layer_vals(i, buf).copy_(dense[r, c])
+            rest = dense.clone()
+            rest[r, c] = 0
+            return float(rest.abs().max()) if rest.numel() else 0.0
         er, ec = self._entry_rc()
-        r, c = er[k0:k1].long(), ec[k0:k1].long()
-        vals = dense[r, c]
-        self.layer_vals(i, buf).copy_(vals)
-        rest = dense.clone()
-        rest[r, c] = 0
-        return float(rest.abs().max()) if rest.numel() else 0.0
+        vals = self.view("dec_vals", buf)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ontovae_dense_to_vals(_ptr(dense), dense.stride(0), _ptr(er), _ptr(ec), int(k0), int(k1), _ptr(vals),
+                                                        self.stream()), "dense_to_vals")
+        on_mask = torch.zeros_like(dense)
+        if k1 > k0:
+            self._scatter_vals(vals, k0, k1, on_mask)
+        return float((dense - on_mask).abs().max()) if dense.numel() else 0.0
 
     def _entry_rc(self):
         if self._idx is None or "er" not in self._idx:
@@ -234,6 +267,7 @@ class Engine:
         return eps
 
     # ------------------------------------------------------------------ entry points
+    @_on_device
     def forward(self, x, xidx=None, eps=None, train=False, want_recon=True):
         x, xidx, B = self._x(x, xidx)
         eps = self._eps(eps, B)
@@ -261,6 +295,7 @@ class Engine:
         a.eps = eps
         return a
 
+    @_on_device
     def train_step(self, x, xidx, eps, kl_coeff, adam, loss_out, apply_update=True):
         x, xidx, B = self._x(x, xidx)
         eps = self._eps(eps, B)
@@ -273,6 +308,7 @@ class Engine:
                                                  float(kl_coeff), C.byref(adam) if adam is not None else None,
                                                  1 if apply_update else 0, _ptr(loss_out), self.stream()), "train_step")
 
+    @_on_device
     def train_step_dp(self, phase, x, xidx, B_global, eps, kl_coeff, bn_stats, bn_bwd_stats, loss_out, offset):
         x, xidx, B = self._x(x, xidx)
         eps = self._eps(eps, B)
@@ -282,12 +318,14 @@ class Engine:
                                                     offset, float(kl_coeff), _ptr(bn_stats), _ptr(bn_bwd_stats),
                                                     _ptr(loss_out), self.stream()), f"train_step_dp phase {phase}")
 
+    @_on_device
     def adamw_apply(self, adam):
         self.ensure_opt_state()
         self.ensure_grad_buffer()
         ctx = self.ctx(max(self.max_batch, 1))
         _lib.check(_lib.lib().ontovae_adamw_apply(C.byref(ctx), C.byref(adam), self.stream()), "adamw_apply")
 
+    @_on_device
     def adamw_apply_range(self, adam, begin, end):
         self.ensure_opt_state()
         self.ensure_grad_buffer()
@@ -295,17 +333,20 @@ class Engine:
         _lib.check(_lib.lib().ontovae_adamw_apply_range(C.byref(ctx), C.byref(adam), int(begin), int(end), self.stream()),
                    "adamw_apply_range")
 
+    @_on_device
     def dp_bn_bwd(self, B, B_global, bn_bwd_stats, offset, send, blm):
         self.ensure_grad_buffer()
         ctx = self.ctx(B)
         _lib.check(_lib.lib().ontovae_dp_bn_bwd(C.byref(ctx), int(B), int(B_global), _ptr(bn_bwd_stats), offset, _ptr(send),
                                                 int(blm), self.stream()), "dp_bn_bwd")
 
+    @_on_device
     def dp_pack_dy(self, B, send, blm):
         """After DP phase 1: this rank's block [dy | b0 slot | xhat | local sums] for the single all-gather."""
         ctx = self.ctx(B)
         _lib.check(_lib.lib().ontovae_dp_pack_dy(C.byref(ctx), int(B), _ptr(send), int(blm), self.stream()), "dp_pack_dy")
 
+    @_on_device
     def dp_dh_global(self, B_global, sizes, blm, gathered, rstride):
         """Global BatchNorm-backward sums and dh of every rank's columns from the all-gathered blocks, in place."""
         sizes = np.ascontiguousarray(sizes, dtype=np.int32)
@@ -313,6 +354,7 @@ class Engine:
         _lib.check(_lib.lib().ontovae_dp_dh_global(C.byref(ctx), int(B_global), len(sizes), sizes.ctypes.data_as(_lib.c_i32p), int(blm),
                                                    _ptr(gathered), int(rstride), self.stream()), "dp_dh_global")
 
+    @_on_device
     def dw0_global(self, x, xidx, colmap, n_ranks, blm, gathered, rstride, adam):
         """dW0 of the global batch from the all-gathered dh blocks (+ the b0 gradient: sum of the blocks' b0 parts);
         adam=None stores the gradient in Gr."""
@@ -324,6 +366,7 @@ class Engine:
                                                  int(rstride), C.byref(adam) if adam is not None else None,
                                                  1 if adam is not None else 0, self.stream()), "dw0_global")
 
+    @_on_device
     def eval_step(self, x, xidx, eps, kl_coeff, loss_out):
         x, xidx, B = self._x(x, xidx)
         eps = self._eps(eps, B)
@@ -331,6 +374,7 @@ class Engine:
         _lib.check(_lib.lib().ontovae_eval_step(C.byref(ctx), _ptr(x), _ptr(xidx), B, _ptr(eps), self.next_offset(),
                                                 float(kl_coeff), _ptr(loss_out), self.stream()), "eval_step")
 
+    @_on_device
     def pass_data(self, x, xidx, eps1, eps2, act_out=None, rec_out=None):
         x, xidx, B = self._x(x, xidx)
         eps1, eps2 = self._eps(eps1, B), self._eps(eps2, B)
@@ -340,6 +384,7 @@ class Engine:
                                                 _ptr(rec_out), rec_out.stride(0) if rec_out is not None else 0, self.stream()),
                    "pass_data")
 
+    @_on_device
     def encode_pre(self, x, xidx, hpre, col0=0):
         """x W0^T of one batch (no bias) into columns [col0, col0 + B) of the feature-major cache hpre [L, ld]."""
         x, xidx, B = self._x(x, xidx)
@@ -349,6 +394,7 @@ class Engine:
         _lib.check(_lib.lib().ontovae_encode_pre(C.byref(ctx), _ptr(x), _ptr(xidx), B, C.c_void_p(hpre.data_ptr() + 4 * col0),
                                                  hpre.stride(0), self.stream()), "encode_pre")
 
+    @_on_device
     def pass_data_perturbed(self, x, xidx, hpre, col0, genes, values, eps1, eps2, act_out=None, rec_out=None, act_fm=None, act_fm_col0=0):
         """pass_data of the batch with columns `genes` of x replaced by `values`, from the cache encode_pre filled.
         act_fm: feature-major [T, ld] matrix whose columns [act_fm_col0, act_fm_col0 + B) receive the activities
@@ -375,6 +421,7 @@ class Engine:
             aptr, ald, afm, _ptr(rec_out),
             rec_out.stride(0) if rec_out is not None else 0, self.stream()), "pass_data_perturbed")
 
+    @_on_device
     def decoder_forward(self, z, act_out=None, rec_out=None):
         z = torch.as_tensor(z, dtype=torch.float32, device=self.device).contiguous()
         if z.dim() != 2 or z.shape[1] != self.plan.L:

@@ -12,8 +12,11 @@ as (dataset, order[i:i+B]): the kernels gather the rows themselves, so there is 
 N x G copy and no per-step host-to-device copy (reference lines 34 and 41,
 onto_vae/vae_model.py:156).
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from .engine import norm_device
 
 
@@ -37,7 +40,16 @@ class FastTensorDataLoader:
     def __iter__(self):
         if self.shuffle:
             r = torch.randperm(self.dataset_len)                       # CPU generator, as the reference
-            self.order = self.order[r.to(self.device)].contiguous()     # cumulative: t[r] on indices
+            if self.device.type == "cuda":                              # cumulative: t[r] on indices (ontovae_compose_order)
+                rd = r.to(self.device)
+                new = torch.empty_like(self.order)
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.lib().ontovae_compose_order(C.c_void_p(self.order.data_ptr()), C.c_void_p(rd.data_ptr()),
+                                                                C.c_void_p(new.data_ptr()), self.dataset_len, self._stream()),
+                               "compose_order")
+                self.order = new
+            else:
+                self.order = self.order[r].contiguous()
         self.i = 0
         return self
 
@@ -53,8 +65,20 @@ class FastTensorDataLoader:
         idx = self.next_indices()
         if idx is None:
             raise StopIteration
-        li = idx.long()
-        return tuple(t.index_select(0, li) for t in self.tensors)
+        return tuple(self._gather(t, idx) for t in self.tensors)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _gather(self, t, idx):
+        """out[b, :] = t[idx[b], :]: ontovae_gather_rows for float32 matrices in HBM, torch indexing for anything else."""
+        if self.device.type != "cuda" or t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous() or t.shape[1] < 1:
+            return t.index_select(0, idx.long())
+        out = torch.empty(idx.shape[0], t.shape[1], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ontovae_gather_rows(C.c_void_p(t.data_ptr()), t.stride(0), C.c_void_p(idx.data_ptr()), idx.shape[0],
+                                                      t.shape[1], C.c_void_p(out.data_ptr()), self._stream()), "gather_rows")
+        return out
 
     def __len__(self):
         return self.n_batches

@@ -59,12 +59,18 @@ def _as_fused(model, optimizer, lr):
         return optimizer
     if optimizer is None:
         return FusedAdamW(model, lr=lr)
-    if isinstance(optimizer, torch.optim.AdamW):   # the reference's call shape: adopt its hyper-parameters
+    if isinstance(optimizer, torch.optim.AdamW):   # the reference's call shape: follow its LIVE hyper-parameters
+        if len(optimizer.param_groups) != 1:
+            raise ValueError("the fused AdamW takes one parameter group (the reference builds one, vae_model.py:251)")
+        g = optimizer.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("amsgrad / maximize are not supported by the fused AdamW")
         f = getattr(optimizer, "_ontovae_fused", None)
         if f is None:
-            g = optimizer.param_groups[0]
-            f = FusedAdamW(model, lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"])
+            f = FusedAdamW(model, lr=g["lr"])
             optimizer._ontovae_fused = f
+        # re-read on every round: an LR scheduler or a manual change between rounds must take effect
+        f.param_groups[0].update(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
         return f
     raise TypeError("optimizer must be onto_vae_amd.vae_model.FusedAdamW (or a torch.optim.AdamW whose settings are adopted)")
 

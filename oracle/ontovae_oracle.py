@@ -57,7 +57,7 @@ def expand_masks(mask_list, nu):
 def nu_mean(a, nu):
     """vae_model.py:297/317: np.array(np.split(a, a.shape[1]/nu, axis=1)).mean(axis=2).T"""
     n, c = a.shape
-    return a.reshape(n, c // nu, nu).mean(axis=2, dtype=F32).astype(F32)
+    return a.reshape(n, c // nu, nu).mean(axis=2, dtype=a.dtype).astype(a.dtype)
 
 
 def train_val_split(n):
@@ -84,9 +84,13 @@ def loader_batches(n, batch_size, perms):
 
 
 class OracleOntoVAE:
-    """Dense CPU OntoVAE with dropout disabled (drop = z_drop = 0), eps supplied."""
+    """Dense CPU OntoVAE, eps supplied; dropout off unless keep-scales are supplied (gradients / train_step).
 
-    def __init__(self, mask_list, neuronnum=3):
+    dtype=np.float64 evaluates the same algorithm in double precision: the yardstick that tells fp32 evaluation-order
+    noise from errors in tests (never the thing compared against for parity; that is the float32 instance)."""
+
+    def __init__(self, mask_list, neuronnum=3, dtype=np.float32):
+        self.dt = np.dtype(dtype).type
         self.nu = int(neuronnum)
         self.mask_list = [np.asarray(m) for m in mask_list]
         self.K = len(mask_list)
@@ -96,7 +100,7 @@ class OracleOntoVAE:
         self.in_features = int(dims[-1])
         d = np.hstack([np.array(dims[:-1]) * self.nu, dims[-1]])   # modules.py:268
         self.layer_shapes = [(int(np.sum(d[:i + 1])), int(d[i + 1])) for i in range(len(d) - 1)]
-        self.masks = expand_masks(self.mask_list, self.nu)
+        self.masks = [m.astype(self.dt) for m in expand_masks(self.mask_list, self.nu)]
         for m, (cin, cout) in zip(self.masks, self.layer_shapes):
             assert m.shape == (cout, cin), (m.shape, cout, cin)
         self.p = {}          # parameters, state_dict names
@@ -116,9 +120,9 @@ class OracleOntoVAE:
 
     def load_state_dict(self, sd):
         for n in self.param_names():
-            self.p[n] = np.array(sd[n], dtype=F32, copy=True)
-        self.buf["running_mean"] = np.array(sd["encoder.encoder.0.1.running_mean"], dtype=F32, copy=True)
-        self.buf["running_var"] = np.array(sd["encoder.encoder.0.1.running_var"], dtype=F32, copy=True)
+            self.p[n] = np.array(sd[n], dtype=self.dt, copy=True)
+        self.buf["running_mean"] = np.array(sd["encoder.encoder.0.1.running_mean"], dtype=self.dt, copy=True)
+        self.buf["running_var"] = np.array(sd["encoder.encoder.0.1.running_var"], dtype=self.dt, copy=True)
         self.buf["num_batches_tracked"] = int(np.asarray(sd["encoder.encoder.0.1.num_batches_tracked"]))
         L, G = self.latent_dim, self.in_features
         assert self.p["encoder.encoder.0.0.weight"].shape == (L, G)
@@ -133,31 +137,39 @@ class OracleOntoVAE:
         return sd
 
     # ---------------------------------------------------------------- forward
-    def encoder_forward(self, x, train):
+    def encoder_forward(self, x, train, scales=None):
+        """scales: None, or (hidden, mu, log_var) keep-scales [B, L] of the three Dropout modules (modules.py:48, 58, 63),
+        values 0 or 1/(1-p); only legal in train mode (nn.Dropout is the identity in eval mode)."""
         p = self.p
+        assert scales is None or train
         h = x @ p["encoder.encoder.0.0.weight"].T + p["encoder.encoder.0.0.bias"]
         if train:
             B = x.shape[0]
             if B < 2:
                 raise ValueError("Expected more than 1 value per channel when training")
-            mean = h.mean(axis=0, dtype=F32)
-            var = ((h - mean) ** 2).mean(axis=0, dtype=F32)          # biased
-            m = F32(BN_MOMENTUM)
-            self.buf["running_mean"] = (F32(1) - m) * self.buf["running_mean"] + m * mean
-            self.buf["running_var"] = (F32(1) - m) * self.buf["running_var"] + m * (var * F32(B / (B - 1)))
+            mean = h.mean(axis=0, dtype=self.dt)
+            var = ((h - mean) ** 2).mean(axis=0, dtype=self.dt)          # biased
+            m = self.dt(BN_MOMENTUM)
+            self.buf["running_mean"] = (self.dt(1) - m) * self.buf["running_mean"] + m * mean
+            self.buf["running_var"] = (self.dt(1) - m) * self.buf["running_var"] + m * (var * self.dt(B / (B - 1)))
             self.buf["num_batches_tracked"] += 1
         else:
             mean, var = self.buf["running_mean"], self.buf["running_var"]
-        invstd = (F32(1) / np.sqrt(var + F32(BN_EPS))).astype(F32)
+        invstd = (self.dt(1) / np.sqrt(var + self.dt(BN_EPS))).astype(self.dt)
         xhat = (h - mean) * invstd
         y = xhat * p["encoder.encoder.0.1.weight"] + p["encoder.encoder.0.1.bias"]
-        a = np.maximum(y, F32(0))
+        if scales is not None:
+            y = y * np.asarray(scales[0], dtype=self.dt)               # BN, then Dropout, then ReLU (modules.py:46-49)
+        a = np.maximum(y, self.dt(0))
         mu = a @ p["encoder.mu.0.weight"].T + p["encoder.mu.0.bias"]
         lv = a @ p["encoder.logvar.0.weight"].T + p["encoder.logvar.0.bias"]
+        if scales is not None:
+            mu = mu * np.asarray(scales[1], dtype=self.dt)             # modules.py:56-64: Dropout(z_drop) after each head
+            lv = lv * np.asarray(scales[2], dtype=self.dt)
         cache = dict(x=x, xhat=xhat, invstd=invstd, y=y, a=a)
-        return mu.astype(F32), lv.astype(F32), cache
+        return mu.astype(self.dt), lv.astype(self.dt), cache
 
-    def decoder_forward(self, z, collect=False):
+    def decoder_forward(self, z, collect=False, gene_layer=True):
         out = z
         outs, cs = [out], []
         for i in range(self.K - 1):
@@ -166,27 +178,27 @@ class OracleOntoVAE:
             out = np.concatenate((c, out), axis=1)                   # new block is PREPENDED
             outs.append(out)
         i = self.K - 1
+        if not gene_layer:
+            return None, outs, cs
         recon = out @ self.p[f"decoder.decoder.{i}.0.weight"].T + self.p[f"decoder.decoder.{i}.0.bias"]
         if collect:
-            return recon.astype(F32), outs, cs
-        return recon.astype(F32)
+            return recon.astype(self.dt), outs, cs
+        return recon.astype(self.dt)
 
-    @staticmethod
-    def reparameterize(mu, lv, eps):
-        return (mu + eps * np.exp(F32(0.5) * lv)).astype(F32)
+    def reparameterize(self, mu, lv, eps):
+        return (mu + eps * np.exp(self.dt(0.5) * lv)).astype(self.dt)
 
     def forward(self, x, eps, train=None):
         train = self.training if train is None else train
-        x = np.asarray(x, dtype=F32)
+        x = np.asarray(x, dtype=self.dt)
         mu, lv, _ = self.encoder_forward(x, train)
-        z = self.reparameterize(mu, lv, np.asarray(eps, dtype=F32))
+        z = self.reparameterize(mu, lv, np.asarray(eps, dtype=self.dt))
         return self.decoder_forward(z), mu, lv
 
-    @staticmethod
-    def vae_loss(recon, mu, lv, x, kl_coeff):
-        kl = F32(-0.5) * np.sum(F32(1) + lv - mu * mu - np.exp(lv), dtype=F32)
-        rec = np.sum((recon - x) ** 2, dtype=F32)
-        return F32(rec), F32(kl), F32(rec + F32(kl_coeff) * kl)
+    def vae_loss(self, recon, mu, lv, x, kl_coeff):
+        kl = self.dt(-0.5) * np.sum(self.dt(1) + lv - mu * mu - np.exp(lv), dtype=self.dt)
+        rec = np.sum((recon - x) ** 2, dtype=self.dt)
+        return self.dt(rec), self.dt(kl), self.dt(rec + self.dt(kl_coeff) * kl)
 
     # --------------------------------------------------------------- training
     def _init_opt(self):
@@ -194,20 +206,21 @@ class OracleOntoVAE:
                     "m": {n: np.zeros_like(v) for n, v in self.p.items()},
                     "v": {n: np.zeros_like(v) for n, v in self.p.items()}}
 
-    def gradients(self, x, eps, kl_coeff):
-        """Forward in train mode + hand-written backward.  Returns (rec, kl, loss, grads)."""
+    def gradients(self, x, eps, kl_coeff, scales=None):
+        """Forward in train mode + hand-written backward.  Returns (rec, kl, loss, grads).
+        scales: dropout keep-scales, see encoder_forward."""
         p, K = self.p, self.K
-        x = np.asarray(x, dtype=F32)
-        eps = np.asarray(eps, dtype=F32)
+        x = np.asarray(x, dtype=self.dt)
+        eps = np.asarray(eps, dtype=self.dt)
         B = x.shape[0]
-        mu, lv, c = self.encoder_forward(x, True)
-        sigma = np.exp(F32(0.5) * lv)
-        z = (mu + eps * sigma).astype(F32)
+        mu, lv, c = self.encoder_forward(x, True, scales)
+        sigma = np.exp(self.dt(0.5) * lv)
+        z = (mu + eps * sigma).astype(self.dt)
         recon, outs, _ = self.decoder_forward(z, collect=True)
         rec, kl, loss = self.vae_loss(recon, mu, lv, x, kl_coeff)
 
         g = {}
-        d_c = F32(2) * (recon - x)                                  # d loss / d recon
+        d_c = self.dt(2) * (recon - x)                                  # d loss / d recon
         d_out = None
         for i in range(K - 1, -1, -1):
             W = p[f"decoder.decoder.{i}.0.weight"]
@@ -215,30 +228,35 @@ class OracleOntoVAE:
                 n_c = W.shape[0]
                 d_c, d_rest = d_out[:, :n_c], d_out[:, n_c:]
             g[f"decoder.decoder.{i}.0.weight"] = d_c.T @ outs[i]
-            g[f"decoder.decoder.{i}.0.bias"] = d_c.sum(axis=0, dtype=F32)
+            g[f"decoder.decoder.{i}.0.bias"] = d_c.sum(axis=0, dtype=self.dt)
             d_prev = d_c @ W
             d_out = d_prev if i == K - 1 else d_rest + d_prev
         d_z = d_out
-        kc = F32(kl_coeff)
+        kc = self.dt(kl_coeff)
         d_mu = d_z + kc * mu
-        d_lv = d_z * eps * F32(0.5) * sigma + kc * F32(0.5) * (np.exp(lv) - F32(1))
+        d_lv = d_z * eps * self.dt(0.5) * sigma + kc * self.dt(0.5) * (np.exp(lv) - self.dt(1))
+        if scales is not None:
+            d_mu = d_mu * np.asarray(scales[1], dtype=self.dt)
+            d_lv = d_lv * np.asarray(scales[2], dtype=self.dt)
         a = c["a"]
         g["encoder.mu.0.weight"] = d_mu.T @ a
-        g["encoder.mu.0.bias"] = d_mu.sum(axis=0, dtype=F32)
+        g["encoder.mu.0.bias"] = d_mu.sum(axis=0, dtype=self.dt)
         g["encoder.logvar.0.weight"] = d_lv.T @ a
-        g["encoder.logvar.0.bias"] = d_lv.sum(axis=0, dtype=F32)
+        g["encoder.logvar.0.bias"] = d_lv.sum(axis=0, dtype=self.dt)
         d_a = d_mu @ p["encoder.mu.0.weight"] + d_lv @ p["encoder.logvar.0.weight"]
         d_y = d_a * (c["y"] > 0)
+        if scales is not None:
+            d_y = d_y * np.asarray(scales[0], dtype=self.dt)
         xhat, invstd = c["xhat"], c["invstd"]
-        g["encoder.encoder.0.1.weight"] = (d_y * xhat).sum(axis=0, dtype=F32)
-        g["encoder.encoder.0.1.bias"] = d_y.sum(axis=0, dtype=F32)
+        g["encoder.encoder.0.1.weight"] = (d_y * xhat).sum(axis=0, dtype=self.dt)
+        g["encoder.encoder.0.1.bias"] = d_y.sum(axis=0, dtype=self.dt)
         d_xhat = d_y * p["encoder.encoder.0.1.weight"]
-        s1 = d_xhat.sum(axis=0, dtype=F32)
-        s2 = (d_xhat * xhat).sum(axis=0, dtype=F32)
-        d_h = (invstd / F32(B)) * (F32(B) * d_xhat - s1 - xhat * s2)
+        s1 = d_xhat.sum(axis=0, dtype=self.dt)
+        s2 = (d_xhat * xhat).sum(axis=0, dtype=self.dt)
+        d_h = (invstd / self.dt(B)) * (self.dt(B) * d_xhat - s1 - xhat * s2)
         g["encoder.encoder.0.0.weight"] = d_h.T @ x
-        g["encoder.encoder.0.0.bias"] = d_h.sum(axis=0, dtype=F32)
-        g = {k: v.astype(F32) for k, v in g.items()}
+        g["encoder.encoder.0.0.bias"] = d_h.sum(axis=0, dtype=self.dt)
+        g = {k: v.astype(self.dt) for k, v in g.items()}
         return rec, kl, loss, g
 
     def adamw(self, grads, lr):
@@ -250,43 +268,48 @@ class OracleOntoVAE:
         t = o["step"]
         bc1 = 1.0 - ADAM_B1 ** t
         bc2 = 1.0 - ADAM_B2 ** t
-        step_size = F32(lr / bc1)
-        bc2_sqrt = F32(math.sqrt(bc2))
+        step_size = self.dt(lr / bc1)
+        bc2_sqrt = self.dt(math.sqrt(bc2))
         for n in self.param_names():
             w, gr, m, v = self.p[n], grads[n], o["m"][n], o["v"][n]
-            w *= F32(1.0 - lr * ADAM_WD)
-            m += (gr - m) * F32(1.0 - ADAM_B1)                       # lerp
-            v *= F32(ADAM_B2)
-            v += F32(1.0 - ADAM_B2) * gr * gr
-            denom = np.sqrt(v) / bc2_sqrt + F32(ADAM_EPS)
+            w *= self.dt(1.0 - lr * ADAM_WD)
+            m += (gr - m) * self.dt(1.0 - ADAM_B1)                       # lerp
+            v *= self.dt(ADAM_B2)
+            v += self.dt(1.0 - ADAM_B2) * gr * gr
+            denom = np.sqrt(v) / bc2_sqrt + self.dt(ADAM_EPS)
             w -= step_size * (m / denom)
 
-    def train_step(self, x, eps, lr, kl_coeff):
-        """One body of train_round (vae_model.py:156-176).  Returns (rec, kl, loss)."""
-        rec, kl, loss, g = self.gradients(x, eps, kl_coeff)
+    def apply_step(self, g, lr):
+        """Gradient mask, AdamW and clamp of one train_round body (vae_model.py:168-176) on gradients from gradients()."""
         for i in range(self.K):                                     # vae_model.py:168-169
             g[f"decoder.decoder.{i}.0.weight"] *= self.masks[i]
         self.adamw(g, lr)                                           # vae_model.py:172
         for i in range(self.K):                                     # vae_model.py:175-176
             n = f"decoder.decoder.{i}.0.weight"
-            self.p[n] = np.maximum(self.p[n], F32(0))
+            self.p[n] = np.maximum(self.p[n], self.dt(0))
+
+    def train_step(self, x, eps, lr, kl_coeff, scales=None):
+        """One body of train_round (vae_model.py:156-176).  Returns (rec, kl, loss)."""
+        rec, kl, loss, g = self.gradients(x, eps, kl_coeff, scales)
+        self.apply_step(g, lr)
         return rec, kl, loss
 
     def val_step(self, x, eps, kl_coeff):
-        x = np.asarray(x, dtype=F32)
+        x = np.asarray(x, dtype=self.dt)
         recon, mu, lv = self.forward(x, eps, train=False)
         return self.vae_loss(recon, mu, lv, x, kl_coeff)
 
     # -------------------------------------------------------------- inference
     def pass_data(self, x, eps1, eps2, output):
-        """vae_model.py:276-327: eval mode, two eps draws, hooks on the first K-1 layers."""
-        x = np.asarray(x, dtype=F32)
+        """vae_model.py:276-327: eval mode, two eps draws, hooks on the first K-1 layers.
+        output 'act_only' is 'act' without evaluating the gene layer (whose result 'act' discards): for large test sizes."""
+        x = np.asarray(x, dtype=self.dt)
         mu, lv, _ = self.encoder_forward(x, False)
-        z1 = self.reparameterize(mu, lv, np.asarray(eps1, dtype=F32))       # get_embedding
+        z1 = self.reparameterize(mu, lv, np.asarray(eps1, dtype=self.dt))       # get_embedding
         z_avg = nu_mean(z1, self.nu)
-        z2 = self.reparameterize(mu, lv, np.asarray(eps2, dtype=F32))       # second forward
-        recon, _, cs = self.decoder_forward(z2, collect=True)
+        z2 = self.reparameterize(mu, lv, np.asarray(eps2, dtype=self.dt))       # second forward
+        recon, _, cs = self.decoder_forward(z2, collect=True, gene_layer=output != "act_only")
         if output == "rec":
             return recon
-        act = np.concatenate(cs, axis=1) if cs else np.zeros((x.shape[0], 0), F32)
-        return np.hstack((z_avg, nu_mean(act, self.nu))).astype(F32)
+        act = np.concatenate(cs, axis=1) if cs else np.zeros((x.shape[0], 0), self.dt)
+        return np.hstack((z_avg, nu_mean(act, self.nu))).astype(self.dt)

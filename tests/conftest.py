@@ -39,15 +39,26 @@ def case(request):
 NOISE_KEYS = ("encoder.encoder.0.0.bias", "encoder.encoder.0.1.running_mean")
 
 
-def act_close(a, b, rel=1e-4, floor=0.1, l2=2e-5):
-    """Activity / reconstruction parity: |a-b| <= rel * max(|b|, tau), tau = floor * max|b|,
-    and relative L2 error <= l2.
+def scaled_err(a, b, tau_frac=1e-3):
+    """max |a - b| / max(|b|, tau), tau = tau_frac * max|b|: the activity metric of SURVEY.md 8(d)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    tau = tau_frac * np.abs(b).max()
+    return float((np.abs(a - b) / np.maximum(np.abs(b), tau)).max())
 
-    SURVEY.md 8(d) proposed tau = 1e-3 * max|b|; that is below the reference's own fp32 noise
-    (outputs near zero are cancelling sums of O(max|b|) terms, so two correct fp32 evaluations
-    in different summation orders already differ by ~3e-7 * max|b|: the oracle-vs-reference
-    fixtures show 1.5e-4 under the tau = 1e-3 rule from reordering alone).  tau = 0.1 * max|b|
-    holds every element >= 10 % of the scale to 1e-4 relative and the rest to 1e-5 of scale.
+
+def act_close(a, b, rel=1e-4, floor=1e-2, l2=2e-5):
+    """Activity / reconstruction parity between two float32 evaluations: |a-b| <= rel * max(|b|, tau),
+    tau = floor * max|b|, and relative L2 error <= l2.
+
+    Where the floor comes from (measured, not assumed): tests/golden/*.npz hold the reference's outputs in float32
+    AND the same reference modules evaluated in float64 (tools/gen_golden.py, keys fwd64/ inf64/).  Under SURVEY.md
+    8(d)'s rule (tau = 1e-3 * max|b|, rel 1e-4) the reference's OWN float32 outputs miss their float64 values by up to
+    1.36e-4 (g1_tiny log_var; 9.0e-5 on recon): elements near zero are cancelling sums of O(max|b|) terms, so their
+    absolute error is ~3e-7 * max|b| whatever their size.  That rule therefore cannot separate two correct fp32
+    evaluations.  At tau = 1e-2 * max|b| the reference's worst scaled error is 1.7e-5, a 6x margin under rel = 1e-4 for the
+    sum of two such errors; that is the floor used here (round 1 used 1e-1).  test_gpu_parity.py::test_error_vs_float64_*
+    additionally hold the HIP path to 2x the reference's own error against float64 under the SURVEY rule itself.
     """
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -56,3 +67,14 @@ def act_close(a, b, rel=1e-4, floor=0.1, l2=2e-5):
     tau = floor * np.abs(b).max()
     ok = bool(np.all(np.abs(a - b) <= rel * np.maximum(np.abs(b), tau)))
     return ok and float(np.linalg.norm(a - b)) <= l2 * float(np.linalg.norm(b)) + 1e-30
+
+
+def close_vs_float64(got, ref32, ref64, factor=2.0, tau_frac=1e-3, rel=1e-4):
+    """Evidence-based parity: `got` (HIP, fp32) may miss the float64 value by at most `factor` times what the reference's
+    own float32 evaluation `ref32` misses it by, in SURVEY.md 8(d)'s scaled metric (tau = 1e-3 * max); and wherever the
+    reference itself meets SURVEY's 1e-4 under that metric, so must `got`.  Returns (ok, got_err, ref_err)."""
+    e_got, e_ref = scaled_err(got, ref64, tau_frac), scaled_err(ref32, ref64, tau_frac)
+    ok = e_got <= factor * e_ref + 1e-7
+    if e_ref <= rel:
+        ok = ok and e_got <= rel
+    return ok, e_got, e_ref

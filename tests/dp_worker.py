@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)      # a hung collective ends the worker with a traceback, not the box's limit
     rank, world, port, path, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -19,17 +21,34 @@ def main():
     from onto_vae_amd.vae_model import OntoVAE, FusedAdamW
     from onto_vae_amd.parallel import dp_train_step
     z = np.load(path, allow_pickle=False)
-    masks = [z[f"mask{i}"] for i in range(int(z["nmask"]))]
+    gobp = "gobp" in z.files          # the full-size model: masks, weights and data regenerated from their seeds, not shipped
+    if gobp:
+        from onto_vae_amd.synthetic import synthetic_masks, synthetic_expression, random_state_dict
+        masks, rng = synthetic_masks(return_rng=True)
+        Xh = synthetic_expression(rng, 2048, 20000).astype(np.float32)
+        sd = random_state_dict(masks, 3, 77, dense=False)
+    else:
+        masks = [z[f"mask{i}"] for i in range(int(z["nmask"]))]
+        Xh = z["X"]
+        sd = {k[3:]: z[k] for k in z.files if k.startswith("sd:")}
     onto = StubOntobj(masks, data={"d": np.zeros((2, masks[-1].shape[0]))})
     torch.manual_seed(0)
     model = OntoVAE(onto, "d", neuronnum=int(z["nu"]), drop=0.0, z_drop=0.0)
     model.to("cuda:0")
-    model.load_state_dict({k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith("sd:")})
-    X = torch.as_tensor(z["X"]).cuda()
+    model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    del sd
+    X = torch.as_tensor(Xh).cuda()
     idx = torch.as_tensor(z["idx"]).cuda()
     eps = torch.as_tensor(z["eps"])
     B = int(z["B"])
     opt = FusedAdamW(model, lr=float(z["lr"]))
+    # start the ranks together on an idle device, as a torchrun-launched training loop does after building its model
+    torch.cuda.synchronize()
+    dist.barrier()
+    trace = os.environ.get("ONTOVAE_DP_WORKER_TRACE") == "1"
+    if trace:
+        import time
+        print(f"[dp_worker {rank}] model ready at {time.time():.1f}", file=sys.stderr, flush=True)
     losses = torch.zeros(steps, 3, device="cuda")
     for s in range(steps):
         ii = idx[s * B:(s + 1) * B]
@@ -37,6 +56,9 @@ def main():
             dp_train_step(model, X, ii, eps[s], 1e-4, opt, losses[s])
         else:
             dp_train_step(model, X[ii.long()], None, eps[s], 1e-4, opt, losses[s])
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[dp_worker {rank}] step {s} done at {time.time():.1f}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     np.savez(path + f".rank{rank}.npz", P=model._engine.P.cpu().numpy(), losses=losses.cpu().numpy())
     dist.destroy_process_group()

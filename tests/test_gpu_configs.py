@@ -1,0 +1,376 @@
+"""GPU parity at the sizes the benchmarks run (BASELINE.json configs[0..3]): the HIP path through the
+C ABI against the dense CPU oracle on the same seeded inputs.
+
+  configs[0]  PWO-shaped model (G = 5892, T = 657, K = 8), train_model(batch_size=128, epochs=5), per-step losses
+  configs[1]  GOBP-syn, B = 128: tests/test_gpu_parity.py::test_gobp_syn_full_size_vs_oracle
+  configs[2]  GOBP-syn train step at B = 1024 / 4096 / 8192 (per-GPU and global batch sizes of the data-parallel runs),
+              and the two-process data-parallel step at global batches that select each exchange form by the heuristic
+  configs[3]  GOBP-syn get_pathway_activities / get_reconstructed_values in 4096- and 16384-row batches
+
+Tolerances: losses 1e-4 relative (north_star); raw gradients 2e-5 of each tensor's scale; activities per
+conftest.act_close (floor 1e-2 of scale, from the float64 evidence in the golden fixtures).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import act_close
+from test_gpu_parity import REL, check_params, feed, hip_state, make_model, medium
+
+pytestmark = pytest.mark.gpu
+
+_GOBP = {}
+
+
+def gobp():
+    """GOBP-syn masks, state_dict and 2048 expression rows (SURVEY.md 8(d) generator), built once per session."""
+    if not _GOBP:
+        from onto_vae_amd.synthetic import synthetic_masks, synthetic_expression, random_state_dict
+        masks, rng = synthetic_masks(return_rng=True)
+        _GOBP["masks"] = masks
+        _GOBP["X"] = synthetic_expression(rng, 2048, 20000).astype(np.float32)
+        _GOBP["sd"] = random_state_dict(masks, 3, 77, dense=False)
+    return _GOBP["masks"], _GOBP["sd"], _GOBP["X"]
+
+
+def grads_of(e):
+    G = e.Gr
+    got = {"encoder.encoder.0.0.weight": e.view("W0", G), "encoder.encoder.0.1.weight": e.view("gamma", G),
+           "encoder.encoder.0.1.bias": e.view("beta", G), "encoder.mu.0.weight": e.view("Wmu", G),
+           "encoder.mu.0.bias": e.view("bmu", G), "encoder.logvar.0.weight": e.view("Wlv", G),
+           "encoder.logvar.0.bias": e.view("blv", G)}
+    for i in range(e.plan.K):
+        got[f"decoder.decoder.{i}.0.bias"] = e.layer_bias(i, G)
+    return got
+
+
+def packed_layer(e, i, dense):
+    """The in-mask entries of a dense [out, in] decoder matrix, in packed order."""
+    k0, k1 = e.plan.layer_entries[i]
+    return dense[e.plan.entry_row[k0:k1], e.plan.entry_col[k0:k1]]
+
+
+def step_vs_oracle(masks, sd, nu, x, eps, lr=1e-4, kc=1e-4):
+    """One training step at batch len(x): raw gradients (apply_update = 0) against the oracle's hand-written backward, then
+    the unfused AdamW and, on a second model, the fused step, both against the oracle's parameters.
+
+    Gradient criterion.  At these batch sizes a gradient element is a sum of thousands of products and two correct float32
+    evaluations differ by more than the 2e-5 of scale that holds at B <= 200 (the oracle's own numpy reductions over the
+    batch axis are sequential).  So the float64 instance of the oracle is the yardstick: per tensor, the HIP path's worst
+    error against float64 may be at most twice the float32 oracle's (floor 2e-6 of the tensor's scale), and never above
+    1e-4 of scale unless the float32 oracle itself is beyond 5e-5 (dW0 at B = 8192 on the medium model: the BatchNorm backward
+    makes every row of dh sum to zero, the gradient is what survives the cancellation, and both float32 evaluations sit at
+    6e-3 of its scale)."""
+    from ontovae_oracle import OracleOntoVAE
+    from onto_vae_amd.vae_model import FusedAdamW
+    o = OracleOntoVAE(masks, nu)
+    o.load_state_dict(sd)
+    rec, kl, loss, g = o.gradients(x, eps, kc)
+    o64 = OracleOntoVAE(masks, nu, dtype=np.float64)
+    o64.load_state_dict(sd)
+    _, _, loss64, g64 = o64.gradients(x, eps, kc)
+    del o64
+    xt, et = torch.as_tensor(x), torch.as_tensor(eps)
+    model, _ = make_model(masks, nu, sd)
+    e = model._engine
+    out = torch.zeros(3, device="cuda")
+    e.train_step(xt, None, et, kc, None, out, apply_update=False)
+    np.testing.assert_allclose(out.cpu().numpy(), [rec, kl, loss], rtol=REL)
+    assert abs(float(out[2]) - loss64) <= max(2 * abs(float(loss) - loss64), 1e-6 * abs(loss64))
+
+    def check(name, got, want32, want64):
+        scale = np.abs(want64).max()
+        e_hip, e_ref = np.abs(got - want64).max() / scale, np.abs(want32 - want64).max() / scale
+        assert e_hip <= max(2 * e_ref, 2e-6) and (e_hip <= 1e-4 or e_ref > 5e-5), (name, e_hip, e_ref)
+
+    for k, v in grads_of(e).items():
+        check(k, v.cpu().numpy(), g[k], g64[k])
+    for i in range(e.plan.K):
+        k = f"decoder.decoder.{i}.0.weight"
+        check(k, e.layer_vals(i, e.Gr).cpu().numpy(), packed_layer(e, i, g[k]), packed_layer(e, i, g64[k]))
+    del g64
+    assert np.abs(e.view("b0", e.Gr).cpu().numpy()).max() <= 1e-4 * np.abs(g["encoder.encoder.0.1.bias"]).max()
+    o.apply_step(g, lr)
+    want_sd = o.state_dict()
+    fused, _ = make_model(masks, nu, sd)
+    fout = torch.zeros(3, device="cuda")
+    fused._engine.train_step(xt, None, et, kc, FusedAdamW(fused, lr=lr).next_hyper(), fout)
+    np.testing.assert_allclose(fout.cpu().numpy(), [rec, kl, loss], rtol=REL)
+    e.adamw_apply(FusedAdamW(model, lr=lr).next_hyper())
+    for m in (model, fused):
+        me = m._engine
+        got = {"W0": me.view("W0").cpu().numpy(), "Wmu": me.view("Wmu").cpu().numpy(), "gamma": me.view("gamma").cpu().numpy(),
+               "rvar": me.rvar.cpu().numpy(), "rmean": me.rmean.cpu().numpy()}
+        want = {"W0": want_sd["encoder.encoder.0.0.weight"], "Wmu": want_sd["encoder.mu.0.weight"],
+                "gamma": want_sd["encoder.encoder.0.1.weight"], "rvar": want_sd["encoder.encoder.0.1.running_var"],
+                "rmean": want_sd["encoder.encoder.0.1.running_mean"]}
+        for i in range(me.plan.K):
+            got[f"dec{i}"] = me.layer_vals(i).cpu().numpy()
+            want[f"dec{i}"] = packed_layer(me, i, want_sd[f"decoder.decoder.{i}.0.weight"])
+            assert got[f"dec{i}"].min() >= 0.0
+        # one step: running statistics are exact arithmetic of this batch (strict), Adam's first step is lr * sign(g)
+        np.testing.assert_allclose(got.pop("rmean"), want.pop("rmean"), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got.pop("rvar"), want.pop("rvar"), rtol=1e-5, atol=1e-6)
+        check_params(got, want, lr, rtol=2e-4, atol=2e-6, outliers=0.01)
+        b0 = me.view("b0").cpu().numpy()
+        assert np.abs(b0 - sd["encoder.encoder.0.0.bias"] * (1 - lr * 1e-2)).max() <= lr * 1.001
+
+
+@pytest.mark.parametrize("B", [1024, 4096, 8192])
+def test_gobp_syn_train_step_large_batches_vs_oracle(B):
+    """BASELINE.json configs[2]: the per-GPU (1024, 4096) and global (8192) batch sizes of the data-parallel runs on the
+    full-size model: dW0 with a K loop, 4-column lanes, 256 column blocks of weight-gradient partials."""
+    masks, sd, X = gobp()
+    rng = np.random.RandomState(B)
+    x = X[rng.randint(0, X.shape[0], size=B)]
+    eps = rng.standard_normal((B, 360)).astype(np.float32)
+    step_vs_oracle(masks, sd, 3, x, eps)
+
+
+@pytest.mark.parametrize("B", [1024, 2048, 8192])
+def test_medium_train_step_large_batches_vs_oracle(B):
+    masks, sd = medium()
+    rng = np.random.RandomState(B + 1)
+    x = np.log1p(rng.poisson(0.5, size=(B, 1000))).astype(np.float32)
+    eps = rng.standard_normal((B, 60)).astype(np.float32)
+    step_vs_oracle(masks, sd, 3, x, eps, lr=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------- configs[3]
+@pytest.mark.parametrize("batch", [4096, 16384])
+def test_gobp_syn_inference_vs_oracle(batch):
+    """get_pathway_activities and get_reconstructed_values on GOBP-syn with `batch` rows per launch set (the kernels that
+    only inference batches select: elementwise eval BatchNorm, LDS-staged heads GEMM, per-level term launches, 64 x 64
+    output transposition) against oracle.pass_data.  The oracle evaluates every row for the activities and the first and
+    last 1024 rows for the reconstruction (each row is independent in eval mode)."""
+    from ontovae_oracle import OracleOntoVAE
+    masks, sd, X = gobp()
+    N = batch
+    rng = np.random.RandomState(batch)
+    rows = rng.randint(0, X.shape[0], size=N)
+    Xd = (X[rows] * rng.uniform(0.5, 1.5, size=(N, 1))).astype(np.float32)      # distinct rows
+    e1 = rng.standard_normal((N, 360)).astype(np.float32)
+    e2 = rng.standard_normal((N, 360)).astype(np.float32)
+    model, onto = make_model(masks, 3, sd, X=Xd)
+    model.inference_batch = batch
+    o = OracleOntoVAE(masks, 3)
+    o.load_state_dict(sd)
+    feed(model, [e1, e2])
+    act = model.get_pathway_activities(onto, "d")
+    assert act.shape == (N, 3000) and act.dtype == np.float32
+    want = o.pass_data(Xd, e1, e2, "act_only")
+    assert act_close(act, want)
+    feed(model, [e1, e2])
+    rec = model.get_reconstructed_values(onto, "d")
+    assert rec.shape == (N, 20000)
+    sel = np.r_[0:1024, N - 1024:N]
+    want = o.pass_data(Xd[sel], e1[sel], e2[sel], "rec")
+    assert act_close(rec[sel], want)
+    # the decoder alone on a supplied z (ontovae_decoder_forward, modules.py:303-313)
+    z = rng.standard_normal((2048, 360)).astype(np.float32)
+    a_out = torch.empty(2048, 3000, device="cuda")
+    r_out = torch.empty(2048, 20000, device="cuda")
+    model._engine.decoder_forward(torch.as_tensor(z), act_out=a_out, rec_out=r_out)
+    recon, _, cs = o.decoder_forward(z, collect=True)
+    from ontovae_oracle import nu_mean
+    want_act = np.hstack((nu_mean(z, 3), nu_mean(np.concatenate(cs, axis=1), 3)))
+    assert act_close(a_out.cpu().numpy(), want_act) and act_close(r_out.cpu().numpy(), recon)
+
+
+# ---------------------------------------------------------------------------------------------- configs[0]
+PWO_COUNTS = [76, 3, 12, 131, 169, 160, 101, 5]      # terms per depth of the trimmed Pathway Ontology
+
+
+def test_pwo_shaped_train_model_vs_oracle(tmp_path, capsys):
+    """BASELINE.json configs[0] (vignette-sized; HPO is not available offline, so the shape of the in-repo Pathway
+    Ontology: G = 5892, T = 657, K = 8, N = 1000): train_model(batch_size=128, epochs=5) = 7 train + 2 val iterations per
+    epoch, per-step rec / kl and per-epoch losses against the oracle walking the same split, shuffle and eps; the printed
+    lines are the reference's (vae_model.py:254, 263, 272-273)."""
+    from ontovae_oracle import OracleOntoVAE, loader_batches, train_val_split
+    from onto_vae_amd.synthetic import synthetic_masks, random_state_dict
+    G, nu, N, B, epochs, lr, kc = 5892, 3, 1000, 128, 5, 1e-4, 1e-4
+    masks = synthetic_masks(PWO_COUNTS, G, 1)
+    assert [m.shape[0] for m in masks[:-1]] == PWO_COUNTS[1:] and masks[-1].shape == (G, 657)
+    sd = random_state_dict(masks, nu, 2)
+    rng = np.random.RandomState(1)
+    X = np.log1p(rng.poisson(0.3, size=(N, G))).astype(np.float64)
+    L = PWO_COUNTS[0] * nu
+    tr, va = train_val_split(N)
+    torch.manual_seed(7)
+    perms = [torch.randperm(len(tr)).numpy() for _ in range(epochs)]
+    train_batches = loader_batches(len(tr), B, perms)
+    val_batches = loader_batches(len(va), B, [None])[0]
+    assert len(train_batches[0]) == 7 and len(val_batches) == 2
+    eps_list, sched = [], []
+    for ep in range(epochs):
+        for b in train_batches[ep]:
+            eps_list.append(rng.standard_normal((len(b), L)).astype(np.float32))
+            sched.append(("train", tr[b], eps_list[-1]))
+        for b in val_batches:
+            eps_list.append(rng.standard_normal((len(b), L)).astype(np.float32))
+            sched.append(("val", va[b], eps_list[-1]))
+    o = OracleOntoVAE(masks, nu)
+    o.load_state_dict(sd)
+    want = {"train": [], "val": []}
+    Xf = X.astype(np.float32)
+    for mode, rows, eps in sched:
+        if mode == "train":
+            want["train"].append(o.train_step(Xf[rows], eps, lr, kc))
+        else:
+            want["val"].append(o.val_step(Xf[rows], eps, kc))
+
+    class Run(dict):
+        class S(list):
+            def log(self, v):
+                self.append(float(v))
+
+        def __missing__(self, k):
+            self[k] = Run.S()
+            return self[k]
+
+    model, _ = make_model(masks, nu, sd, X=X)
+    feed(model, eps_list)
+    run = Run()
+    torch.manual_seed(7)
+    path = tmp_path / "best.pt"
+    model.train_model(str(path), lr=lr, kl_coeff=kc, batch_size=B, epochs=epochs, run=run)
+    printed = capsys.readouterr().out.splitlines()
+    wt, wv = np.array(want["train"], dtype=np.float64), np.array(want["val"], dtype=np.float64)
+    np.testing.assert_allclose(run["metrics/train/rec_loss"], wt[:, 0], rtol=REL)
+    np.testing.assert_allclose(run["metrics/train/kl_loss"], wt[:, 1], rtol=REL)
+    # Validation inside train_model runs on trained weights, and eval-mode BatchNorm sees the Linear bias in front of it
+    # through (b0 - running_mean).  That bias has an analytically zero gradient; Adam turns its rounding noise into
+    # +-lr steps (NOISE_KEYS), so after n steps two correct float32 implementations -- the reference on
+    # two machines included -- differ in b0 - running_mean by up to ~9 lr (the EMA lag) and in the validation losses by a
+    # few 1e-4.  Held to 2e-3 here, and to 1e-4 below on IDENTICAL weights.
+    VAL = 2e-3
+    np.testing.assert_allclose(run["metrics/val/rec_loss"], wv[:, 0], rtol=VAL)
+    np.testing.assert_allclose(run["metrics/val/kl_loss"], wv[:, 1], rtol=VAL)
+    ep_train = wt[:, 2].reshape(epochs, 7).mean(1)
+    ep_val = wv[:, 2].reshape(epochs, 2).mean(1)
+    np.testing.assert_allclose(run["metrics/train/loss"], ep_train, rtol=REL)
+    np.testing.assert_allclose(run["metrics/val/loss"], ep_val, rtol=VAL)
+    # printed protocol: "Epoch i of n", "New best model!" when the validation loss improves, then the two loss lines
+    got_val = run["metrics/val/loss"]
+    best, it = float("inf"), iter(printed)
+    for ep in range(epochs):
+        assert next(it) == f"Epoch {ep + 1} of {epochs}"
+        if got_val[ep] < best:
+            assert next(it) == "New best model!"
+            best = got_val[ep]
+        t, v = next(it), next(it)
+        assert t.startswith("Train Loss: ") and v.startswith("Val Loss: ")
+        np.testing.assert_allclose(float(t.split(": ")[1]), ep_train[ep], rtol=REL, atol=1e-4)
+        np.testing.assert_allclose(float(v.split(": ")[1]), got_val[ep], rtol=1e-6, atol=1e-4)
+        assert len(t.split(".")[-1]) == 4
+    assert next(it, None) is None
+    # val_round at this shape on identical weights: the oracle's trained state loaded into a fresh model
+    vmodel, _ = make_model(masks, nu, {k: np.asarray(v) for k, v in o.state_dict().items()}, X=X)
+    veps = [rng.standard_normal((len(b), L)).astype(np.float32) for b in val_batches]
+    feed(vmodel, list(veps))
+    vrun = Run()
+    vloss = vmodel.val_round([(torch.as_tensor(Xf[va[b]]),) for b in val_batches], kc, vrun)
+    vwant = np.array([o.val_step(Xf[va[b]], e_, kc) for b, e_ in zip(val_batches, veps)], dtype=np.float64)
+    np.testing.assert_allclose(vrun["metrics/val/rec_loss"], vwant[:, 0], rtol=REL)
+    np.testing.assert_allclose(vrun["metrics/val/kl_loss"], vwant[:, 1], rtol=REL)
+    np.testing.assert_allclose(vloss, vwant[:, 2].mean(), rtol=REL)
+    ck = torch.load(str(path), weights_only=True)
+    assert set(ck) >= {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
+    np.testing.assert_allclose(ck["loss"], min(got_val), rtol=1e-6)
+    steps = epochs * 7
+    check_params(hip_state(model), o.state_dict(), steps * lr, rtol=2e-4, atol=2e-6, outliers=0.01)
+
+
+# ---------------------------------------------------------------------------------------------- configs[2], data parallel
+def test_dp_allreduce_form_gobp_syn_global_8192():
+    """configs[2] proper: global batch 8192 on the full-size model in the all-reduce form that use_gathered_dh selects there
+    (2, 4 and 8 ranks), as two simulated ranks of 4096 rows on one GPU with the collectives done by hand
+    (ontovae_train_step_dp phases 0 / 1 with all-gathered statistics / 2, SUM of the flat gradient buffers, flat AdamW):
+    must land where the single-device step on the global batch lands (held to the oracle above), replicas identical.
+    The same exchange through onto_vae_amd.parallel.dp_train_step and real collectives runs in
+    test_gpu_parity.py::test_dp_two_processes_one_gpu (medium model) and, in the gathered form at full size, below; two
+    PROCESSES at 4096 rows each on one shared GPU are not run: host-staged gloo copies next to these kernels stalled for
+    minutes on the test box."""
+    from onto_vae_amd.parallel import use_gathered_dh
+    from onto_vae_amd.vae_model import FusedAdamW
+    for world in (2, 4, 8):
+        assert not use_gathered_dh(8192, world, 360, 20000)
+        assert use_gathered_dh(128 * world, world, 360, 20000)
+    masks, sd, X = gobp()
+    B, L, kc, lr = 8192, 360, 1e-4, 1e-4
+    rng = np.random.RandomState(8192 + 5)
+    Xd = torch.as_tensor(X).cuda()
+    idx = torch.as_tensor(rng.randint(0, X.shape[0], size=B).astype(np.int32)).cuda()
+    eps = torch.as_tensor(rng.standard_normal((B, L)).astype(np.float32)).cuda()
+    ref, _ = make_model(masks, 3, sd)
+    rout = torch.zeros(3, device="cuda")
+    ref._engine.train_step(Xd, idx, eps, kc, FusedAdamW(ref, lr=lr).next_hyper(), rout)
+    ranks = [make_model(masks, 3, sd)[0] for _ in range(2)]
+    parts = [(0, 4096), (4096, 8192)]
+    stats = [torch.zeros(2 * L + 1, device="cuda") for _ in ranks]
+    bstats = [torch.zeros(2, L, device="cuda") for _ in ranks]
+    louts = [torch.zeros(3, device="cuda") for _ in ranks]
+    for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+        stats[r][2 * L] = float(b - a)
+        m._engine.train_step_dp(0, Xd, idx[a:b], B, eps[a:b], kc, stats[r][:2 * L].view(2, L), bstats[r], louts[r], 1)
+    gathered = torch.cat(stats)
+    for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+        m._engine.train_step_dp(16 + 2, Xd, idx[a:b], B, eps[a:b], kc, gathered, bstats[r], louts[r], 1)
+    bsum = bstats[0] + bstats[1]
+    for r, (m, (a, b)) in enumerate(zip(ranks, parts)):
+        bstats[r].copy_(bsum)
+        m._engine.train_step_dp(2, Xd, idx[a:b], B, eps[a:b], kc, stats[r][:2 * L].view(2, L), bstats[r], louts[r], 1)
+    gsum = ranks[0]._engine.Gr + ranks[1]._engine.Gr
+    np.testing.assert_allclose((louts[0] + louts[1])[:2].cpu().numpy(), rout[:2].cpu().numpy(), rtol=1e-5)
+    for m in ranks:
+        m._engine.Gr.copy_(gsum)
+        m._engine.adamw_apply(FusedAdamW(m, lr=lr).next_hyper())
+    assert torch.equal(ranks[0]._engine.P, ranks[1]._engine.P)
+    e = ref._engine
+    want, got = e.P.cpu().numpy(), ranks[0]._engine.P.cpu().numpy()
+    keep = np.ones(want.shape, bool)
+    keep[int(e.plan.layout.b0):int(e.plan.layout.b0) + L] = False
+    diff = np.abs(got - want)[keep]
+    assert (diff > 1e-6 + 1e-4 * np.abs(want[keep])).mean() <= 0.01 and diff.max() <= 2 * lr
+
+
+@pytest.mark.parametrize("B,form", [(1024, "gathered")])
+def test_dp_two_processes_gobp_syn_heuristic_forms(tmp_path, B, form):
+    """onto_vae_amd.parallel.dp_train_step on the full-size model, two processes on GPU 0 over gloo, exchange form chosen by
+    use_gathered_dh itself: global batch 1024 -> all-gathered dh and dW0 over 8 chunks of the K loop on every rank.  One
+    step must land where the single-process step on the global batch lands (itself held to the oracle above), replicas
+    bitwise identical."""
+    from onto_vae_amd.parallel import use_gathered_dh
+    from onto_vae_amd.vae_model import FusedAdamW
+    assert use_gathered_dh(B, 2, 360, 20000) == (form == "gathered")
+    masks, sd, X = gobp()
+    rng = np.random.RandomState(B + 5)
+    idx = rng.randint(0, X.shape[0], size=B).astype(np.int32)
+    eps = rng.standard_normal((1, B, 360)).astype(np.float32)
+    path = str(tmp_path / "dp_gobp.npz")
+    np.savez(path, gobp=1, nu=3, idx=idx, eps=eps, B=B, lr=1e-4, use_idx=1)
+    ref, _ = make_model(masks, 3, sd)
+    rl = torch.zeros(1, 3, device="cuda")
+    Xd = torch.as_tensor(X).cuda()
+    ref._engine.train_step(Xd, torch.as_tensor(idx).cuda(), torch.as_tensor(eps[0]), 1e-4, FusedAdamW(ref, lr=1e-4).next_hyper(), rl[0])
+    want = ref._engine.P.cpu().numpy()
+    lay, Lw = ref._engine.plan.layout, ref._engine.plan.L
+    del ref, Xd
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("ONTOVAE_DP_ALLREDUCE", "ONTOVAE_DP_TWO_EXCHANGES")}
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker.py")
+    port = str(29900 + (os.getpid() % 90))
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, path, "1"], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=170) == 0
+    got = [np.load(path + f".rank{r}.npz") for r in range(2)]
+    assert np.array_equal(got[0]["P"], got[1]["P"])
+    np.testing.assert_allclose(got[0]["losses"], rl.cpu().numpy(), rtol=2e-5)
+    mask = np.ones(want.shape, bool)
+    mask[int(lay.b0):int(lay.b0) + Lw] = False
+    diff = np.abs(got[0]["P"] - want)[mask]
+    assert (diff > 1e-6 + 1e-4 * np.abs(want[mask])).mean() <= 0.01 and diff.max() <= 2 * 1e-4

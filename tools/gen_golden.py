@@ -30,11 +30,12 @@ from onto_vae_amd.synthetic import (StubOntobj, synthetic_links, links_to_masks,
 
 
 class EpsQueue:
-    def __init__(self):
+    def __init__(self, dtype=torch.float32):
         self.q = []
+        self.dtype = dtype
 
     def push(self, e):
-        self.q.append(torch.tensor(e, dtype=torch.float32))
+        self.q.append(torch.tensor(e, dtype=self.dtype))
 
     def __call__(self, mu, log_var):
         eps = self.q.pop(0)
@@ -59,15 +60,34 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
-def build_ref(masks, nu, sd_np, X=None):
+def build_ref(masks, nu, sd_np, X=None, dtype=torch.float32, drop=0.0, z_drop=0.0):
     onto = StubOntobj(masks, data={"d": X if X is not None else np.zeros((2, masks[-1].shape[0]))})
     torch.manual_seed(0)
-    model = RefOntoVAE(onto, "d", neuronnum=nu, drop=0.0, z_drop=0.0)
+    model = RefOntoVAE(onto, "d", neuronnum=nu, drop=drop, z_drop=z_drop)
     sd = {k: torch.tensor(v) for k, v in sd_np.items()}
     model.load_state_dict(sd)
-    epsq = EpsQueue()
+    if dtype != torch.float32:
+        model = model.to(dtype)
+    epsq = EpsQueue(dtype)
     model.reparameterize = epsq
     return model, onto, epsq
+
+
+class FixedDropout(torch.nn.Module):
+    """nn.Dropout with the keep-scales supplied: train mode multiplies by the next queued array of {0, 1/(1-p)},
+    eval mode is the identity (what nn.Dropout does).  Stands in for the reference's Dropout modules
+    (onto_vae/modules.py:48, 58, 63) so that the dropout-on golden set is reproducible."""
+
+    def __init__(self):
+        super().__init__()
+        self.q = []
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        s = self.q.pop(0)
+        assert s.shape == x.shape
+        return x * s
 
 
 def gen_case(name, counts, G, nu, seed, B, steps, out_dir, lr=1e-3, kl_coeff=1e-4, n_inf=11, last_B=None):
@@ -157,9 +177,88 @@ def gen_case(name, counts, G, nu, seed, B, steps, out_dir, lr=1e-3, kl_coeff=1e-
     fx["inf/pert_rec"] = model.perturbation(onto, "inf", pg, [0.0, 2.5], output="genes")
     assert fx["inf/act"].shape == (n_inf, T)
 
+    # ---- the same outputs from the reference modules in float64 (model.double()): the yardstick for what fp32
+    # evaluation order alone costs (tests: error of the HIP path against these vs the reference's own fp32 error)
+    m64, _, epsq64 = build_ref(masks, nu, sd0, dtype=torch.float64)
+    m64.train()
+    epsq64.push(epss[0].astype(np.float64))
+    with torch.no_grad():
+        r64, mu64, lv64 = m64.forward(torch.tensor(xs[0], dtype=torch.float64))
+    fx["fwd64/recon"], fx["fwd64/mu"], fx["fwd64/log_var"] = r64.numpy(), mu64.numpy(), lv64.numpy()
+    sdT = {k[4:]: v for k, v in fx.items() if k.startswith("sdT/")}
+    m64, _, epsq64 = build_ref(masks, nu, sdT, dtype=torch.float64)
+    Xp = Xd.copy()
+    Xp[:, 3], Xp[:, G // 2] = 0.0, 2.5
+    for key, data, what in (("inf64/act", Xd, "act"), ("inf64/rec", Xd, "rec"), ("inf64/pert_act", Xp, "act"),
+                            ("inf64/pert_rec", Xp, "rec")):
+        epsq64.push(e1.astype(np.float64)); epsq64.push(e2.astype(np.float64))
+        fx[key] = m64._pass_data(torch.tensor(data, dtype=torch.float64), what)
+        assert fx[key].dtype == np.float64
+
     path = os.path.join(out_dir, f"{name}.npz")
     np.savez_compressed(path, **fx)
     print(f"{name}: K={len(masks)} G={G} L={L} T={T} steps={steps} -> {path} ({os.path.getsize(path)/1e3:.0f} kB)")
+    return fx, masks
+
+
+def gen_dropout_case(name, counts, G, nu, seed, B, steps, out_dir, drop=0.2, z_drop=0.5, lr=1e-3, kl_coeff=1e-4):
+    """Dropout ON (the reference's defaults drop=0.2, z_drop=0.5, vae_model.py:40) with the three Dropout modules of the
+    reference Encoder replaced by FixedDropout: per step the keep-scales of the hidden layer [B, L] and of mu / log_var
+    [B, L] are inputs of the fixture.  Records the gradients after the first step and `steps` train_round bodies."""
+    rng = np.random.RandomState(seed)
+    off, tp, gp = synthetic_links(counts, G, rng)
+    masks = links_to_masks(off, tp, gp)
+    sd0 = random_state_dict(masks, nu, seed + 1)
+    L = counts[0] * nu
+    xs = [np.log1p(rng.poisson(0.8, size=(B, G))).astype(np.float32) for _ in range(steps)]
+    epss = [rng.standard_normal(size=(B, L)).astype(np.float32) for _ in range(steps)]
+
+    def scales(p):
+        keep = rng.uniform(size=(B, L)) >= p
+        return (keep.astype(np.float32) * np.float32(1.0 / (1.0 - p))).astype(np.float32)
+
+    sc = [(scales(drop), scales(z_drop), scales(z_drop)) for _ in range(steps)]
+    fx = {"nu": np.int64(nu), "K": np.int64(len(masks)), "lr": np.float64(lr), "kl_coeff": np.float64(kl_coeff),
+          "steps": np.int64(steps), "counts": np.array(counts, dtype=np.int64), "drop": np.float64(drop), "z_drop": np.float64(z_drop)}
+    for i, m in enumerate(masks):
+        fx[f"mask/{i}"] = m.astype(np.int8)
+    for k, v in sd0.items():
+        fx[f"sd0/{k}"] = v
+    for s in range(steps):
+        fx[f"x/{s}"], fx[f"eps/{s}"] = xs[s], epss[s]
+        fx[f"drop_scale/{s}"], fx[f"zmu_scale/{s}"], fx[f"zlv_scale/{s}"] = sc[s]
+
+    model, onto, epsq = build_ref(masks, nu, sd0, drop=drop, z_drop=z_drop)
+    fd = [FixedDropout(), FixedDropout(), FixedDropout()]
+    assert isinstance(model.encoder.encoder[0][2], torch.nn.Dropout) and isinstance(model.encoder.mu[1], torch.nn.Dropout)
+    model.encoder.encoder[0][2], model.encoder.mu[1], model.encoder.logvar[1] = fd
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    run = RunRecorder()
+    losses = []
+    for s in range(steps):
+        epsq.push(epss[s])
+        for f, a in zip(fd, sc[s]):
+            f.q.append(torch.tensor(a))
+        losses.append(quiet(model.train_round, [(torch.tensor(xs[s]),)], lr, kl_coeff, opt, run))
+        if s == 0:
+            for n, p_ in model.named_parameters():
+                fx[f"grad0/{n}"] = p_.grad.detach().numpy().copy()       # after the gradient mask (vae_model.py:168-169)
+    fx["train/loss"] = np.array(losses, dtype=np.float64)
+    fx["train/rec"] = np.array(run["metrics/train/rec_loss"], dtype=np.float64)
+    fx["train/kl"] = np.array(run["metrics/train/kl_loss"], dtype=np.float64)
+    for k, v in model.state_dict().items():
+        fx[f"sdT/{k}"] = v.detach().numpy().copy()
+    # eval mode: the Dropout modules are the identity
+    xv = np.log1p(rng.poisson(0.8, size=(7, G))).astype(np.float32)
+    ev = rng.standard_normal(size=(7, L)).astype(np.float32)
+    epsq.push(ev)
+    runv = RunRecorder()
+    vloss = quiet(model.val_round, [(torch.tensor(xv),)], kl_coeff, runv)
+    fx["val/x"], fx["val/eps"] = xv, ev
+    fx["val/rec_kl_loss"] = np.array([runv["metrics/val/rec_loss"][0], runv["metrics/val/kl_loss"][0], vloss])
+    path = os.path.join(out_dir, f"{name}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: dropout {drop}/{z_drop}, steps={steps} -> {path} ({os.path.getsize(path)/1e3:.0f} kB)")
     return fx, masks
 
 
@@ -219,4 +318,5 @@ if __name__ == "__main__":
     check_oracle(fx, masks)
     fx, masks = gen_case("g1_nu1", counts=[5, 4], G=31, nu=1, seed=303, B=5, steps=4, out_dir=a.out, n_inf=3)
     check_oracle(fx, masks)
+    gen_dropout_case("g1_drop", counts=[6, 9, 7], G=120, nu=3, seed=404, B=24, steps=4, out_dir=a.out)
     gen_loader(a.out)
