@@ -185,8 +185,7 @@ typedef struct ontovae_ctx {
 #define ONTOVAE_FLAG_LEVEL_LAUNCHES 1u  /* one launch per decoder level instead of the LDS-fused chain */
 #define ONTOVAE_FLAG_ROW_GENE_LAYER 2u  /* row-per-wave gene layer instead of the LDS-tiled one */
 #define ONTOVAE_FLAG_WIDE_GENE_TILES 8u /* gene layer: waves that span 64-256 batch columns instead of XCD-pinned 32-column blocks */
-/* Bits 5 and above are measurement switches of the scripts under scratch/ (skip a kernel's main loop, epilogue, record refill ...):
- * results are undefined with any of them set.  Leave them 0. */
+/* Any other bit is refused with ONTOVAE_EINVAL (measurement switches exist only in -DOV_MEASUREMENT_SWITCHES builds). */
 #define ONTOVAE_FLAG_NO_RIDERS     16u  /* weight gradient of the gene rows as its own launch instead of inside the backward chain's */
 #define ONTOVAE_FLAG_SIDE_STREAM    4u  /* run the decoder weight gradient and dWh on a library-owned second stream, forked from
                                            and joined into the caller's stream with events (off by default: on this pool the event

@@ -10,6 +10,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define OV_WAVE 64
 
+// Measurement switches (skip a kernel's main loop, select an experimental variant ...) are read from the upper bits of
+// ctx->flags only in builds with -DOV_MEASUREMENT_SWITCHES; the shipped library compiles them out (every OV_DBG(...) is the
+// constant 0, the branches it guards disappear) and ov_check_ctx refuses flag bits it does not know.
+#ifdef OV_MEASUREMENT_SWITCHES
+#define OV_DBG(expr) (expr)
+#else
+#define OV_DBG(expr) 0
+#endif
+
 __device__ __forceinline__ int ov_lane() { return threadIdx.x & 63; }
 // wave index inside the block as a scalar (SGPR) value, so that everything indexed by it is loaded
 // through the scalar path

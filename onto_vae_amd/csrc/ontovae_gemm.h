@@ -153,7 +153,7 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
             }
     }
 
-    if (tile_on && kbeg < kend && !(p.dbg & 1)) {
+    if (tile_on && kbeg < kend && !(OV_DBG(p.dbg) & 1)) {
         // per-lane operand bases (rows clamped: out-of-range rows are computed and never stored)
         const float* abase[MT];
         const float* bbase[NT];
@@ -177,7 +177,7 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
         }
         f32x4 a[2][UK][MT], b[2][UK][NT];
         auto load_batch = [&](int buf, int k0) {
-            if (p.dbg & 4) {      // measurement only: no global loads, MFMA pace alone
+            if (OV_DBG(p.dbg) & 4) {      // measurement only: no global loads, MFMA pace alone
 #pragma unroll
                 for (int u = 0; u < UK; ++u) {
 #pragma unroll
@@ -273,7 +273,7 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
     }
     if (!tile_on) return;
 
-    if (p.dbg & 2) {
+    if (OV_DBG(p.dbg) & 2) {
         float sink = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -604,7 +604,7 @@ __device__ __forceinline__ ov_i32x4 ov_buf_rsrc(const void* base, uint32_t bytes
     return r;
 }
 
-#ifdef OV_DW0_PROBE      // scratch/dw0_probe.hip: per-wave timestamps into p.bias (16 x uint64 per wave)
+#ifdef OV_DW0_PROBE      // probe builds only: per-wave timestamps into p.bias (16 x uint64 per wave)
 #define OV_PROBE(slot) do { probe_t[slot] = __builtin_readcyclecounter(); } while (0)
 #else
 #define OV_PROBE(slot) do { } while (0)

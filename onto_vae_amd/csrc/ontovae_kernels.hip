@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #define OV_HIP_CHECK(expr)                                                                       \
     do {                                                                                         \
@@ -22,6 +23,8 @@
     } while (0)
 
 #define OV_LAUNCH_CHECK() OV_HIP_CHECK(hipGetLastError())
+
+#define OV_KNOWN_FLAGS (ONTOVAE_FLAG_LEVEL_LAUNCHES | ONTOVAE_FLAG_ROW_GENE_LAYER | ONTOVAE_FLAG_SIDE_STREAM | ONTOVAE_FLAG_WIDE_GENE_TILES | ONTOVAE_FLAG_NO_RIDERS)
 
 // batch columns per wave pass (64 lanes x VEC) and the padded row length, a multiple of it
 // -------------------------------------------------------------------------------------------------
@@ -845,15 +848,6 @@ __global__ __launch_bounds__(256) void ov_sell_refresh_kernel(const OvRefresh rf
 // lanes that share a node, one store to LDS and one to the feature-major matrix in HBM.
 //   FWD: out = bias + sum w * panel[idx]      BWD: out = D (gene part, from HBM) + sum w * dpanel[idx]
 // -------------------------------------------------------------------------------------------------
-#ifdef OV_CHAIN_PROBE    // scratch/chain_probe.py: per-wave timestamps of the first 4 workgroups
-__device__ unsigned long long ov_chain_probe_buf[2 * 4 * 16 * 32];
-#define OV_CPROBE(slot) do { if (blockIdx.x < 4 && lane == 0 && (slot) < 32) ov_chain_probe_buf[(((BWD ? 4 : 0) + blockIdx.x) * 16 + wave) * 32 + (slot)] = __builtin_readcyclecounter(); } while (0)
-extern "C" int ontovae_debug_chain_probe(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ov_chain_probe_buf), sizeof(ov_chain_probe_buf)) == hipSuccess ? 0 : -1;
-}
-#else
-#define OV_CPROBE(slot) do { } while (0)
-#endif
 #ifndef OV_CHAIN_DEPTH
 #define OV_CHAIN_DEPTH 3     // records in flight per wave (19 registers each; 16 waves per CU leave 128 per lane)
 #endif
@@ -897,12 +891,11 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
     const float* __restrict__ sbias = ca.sbias;
     float* __restrict__ glob = ca.glob;
     const float* __restrict__ inblk = ca.inblk;
-    const int ldb = ca.ldb, in0 = ca.in0, in1 = ca.in1, out0 = ca.out0, out1 = ca.out1, dbg = ca.dbg;
+    const int ldb = ca.ldb, in0 = ca.in0, in1 = ca.in1, out0 = ca.out0, out1 = ca.out1, dbg = OV_DBG(ca.dbg);
     extern __shared__ __attribute__((aligned(16))) float ov_panel[];
     const int b0 = block * BT;
     const int lane = ov_lane();
     const int wave = ov_wave_id();
-    OV_CPROBE(0);
 
     // Records are requested OV_CHAIN_DEPTH steps ahead, across level boundaries: a step's own work (a few LDS
     // gathers) is far shorter than the memory round trip of its record.  Every request is unconditional (a
@@ -931,10 +924,8 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
         for (int u = 0; u < 8; ++u)
             if (p + u * 1024 < in1) ov_stv<BT>(ov_panel + (int64_t)(p + u * 1024) * BT, v[u]);
     }
-    OV_CPROBE(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    OV_CPROBE(2);
 
     for (int q0 = 0; q0 < st.n; q0 += OV_CHAIN_DEPTH) {
 #pragma unroll
@@ -946,7 +937,6 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
                     // LDS writes of the level must land before the next level reads them
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    OV_CPROBE(3 + (q < 28 ? q : 28));
                 }
                 const int sl = (bq & ~OV_STEP_NEW_LEVEL) + wave;
                 if (sl < st.end[q] && !(dbg & 2)) {                // uniform over the wave
@@ -1006,7 +996,6 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    OV_CPROBE(30);
 
     // epilogue: results LDS -> HBM (feature-major), for the gene layer and the weight gradient
     if (!(dbg & 1))
@@ -1015,7 +1004,6 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
         ov_ldv<BT>(ov_panel + (int64_t)p * BT, v);
         ov_stv<BT>(glob + (int64_t)p * ldb + b0, v);
     }
-    OV_CPROBE(31);
 }
 
 template <int BT, bool BWD, bool SINGLE>
@@ -1960,6 +1948,12 @@ static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
                           (long long)ov_carve(d, c->max_batch, nullptr, nullptr));
         return ONTOVAE_EINVAL;
     }
+#ifndef OV_MEASUREMENT_SWITCHES
+    if (c->flags & ~(uint32_t)OV_KNOWN_FLAGS) {
+        ontovae_set_error("ctx: unknown flag bits 0x%x (known: 0x%x)", c->flags & ~(uint32_t)OV_KNOWN_FLAGS, (unsigned)OV_KNOWN_FLAGS);
+        return ONTOVAE_EINVAL;
+    }
+#endif
     if ((reinterpret_cast<uintptr_t>(c->workspace) & 255) || (reinterpret_cast<uintptr_t>(c->P) & 15)) {
         ontovae_set_error("ctx: workspace must be 256-B aligned and P 16-B aligned");
         return ONTOVAE_EINVAL;
@@ -2081,6 +2075,8 @@ static OvSide* ov_side_get(const ontovae_ctx_t* c) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     OvSide& s = g_side[dev];
+    static std::mutex init_mutex;
+    std::lock_guard<std::mutex> lock(init_mutex);
     if (!s.tried) {
         s.tried = true;
         s.ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
@@ -2128,13 +2124,13 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     g.C = s.ws.slab; g.ldc = s.ldb; g.slab_stride = (int64_t)d.L * s.ldb; g.kchunk = kchunk;
     const bool vec = (d.G % 4 == 0) && (s.xld % 4 == 0) && ov_al16(g.A) && ov_al16(g.B);
     *S_out = Seff;
-    g.dbg = (s.c->flags >> 18) & 3;
+    g.dbg = OV_DBG((s.c->flags >> 18) & 3);
     OvProfScope prof(ONTOVAE_PHASE_ENC_GEMM, s.st);
     const int nt = ov_enc_nt(s.B);
-    if (vec && nt == 4 && !((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds<1, 4, true, OV_EPI_STORE>(g, Seff, s.st);
+    if (vec && nt == 4 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds<1, 4, true, OV_EPI_STORE>(g, Seff, s.st);
     if (nt == 1) return ov_launch_gemm<3, 1, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
     if (nt == 2) return ov_launch_gemm<3, 2, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
-    if ((s.c->flags >> 14) & 1) return ov_launch_gemm<3, 4, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
+    if (OV_DBG((s.c->flags >> 14) & 1)) return ov_launch_gemm<3, 4, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
     return ov_launch_gemm<3, 4, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
 }
 
@@ -2306,7 +2302,7 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     const size_t lds = (size_t)d.C * bt * sizeof(float);
     OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
     const OvChainArgs ca{f.node, f.info, f.chunk0, f.idx, f.w, f.bias, s.ws.act, nullptr, s.ldb, d.C - d.L, d.C, 0, d.C - d.L,
-                         (int)((c->flags >> 8) & 7)};
+                         (int)OV_DBG((c->flags >> 8) & 7)};
 #define OV_TF2(BT, SG)                                                                                                \
     if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false, SG>, lds))) return rc;                                         \
     hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, ca, lv)
@@ -2405,7 +2401,7 @@ static int ov_dec_backward(OvStep& s, const OvWgradArgs* wg = nullptr, bool* wg_
     const size_t lds = (size_t)d.C * bt * sizeof(float);
     OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
     const OvChainArgs ca{sb.node, sb.info, sb.chunk0, sb.idx, sb.w, nullptr, s.ws.d, blk, s.ldb, 0, d.C, 0, d.C,
-                         (int)((c->flags >> 8) & 7)};
+                         (int)OV_DBG((c->flags >> 8) & 7)};
     const int nchain = s.ldb / bt;
     const int wteams = wg ? ov_cb_grid(wg->ncb, wg->ntiles) : 0;
 #define OV_TB2(BT, SG)                                                                                                \
@@ -2836,7 +2832,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         OV_LAUNCH_CHECK();
         return ONTOVAE_OK;
     }
-    const bool dwh_main = (c->flags & 64u) != 0;
+    const bool dwh_main = OV_DBG((c->flags & 64u) != 0);
     if (!dwh_main && (rc = ov_side_sync_mid(s))) return rc;
     {
         const hipStream_t wst = dwh_main ? s.st : ov_side_stream(s);
@@ -2862,16 +2858,16 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     g.B = s.x; g.ldb = s.xld; g.bgather = s.xidx;     // B(k=b, n=g) = X[row(b) * G + g]
     g.ldc = d.G; g.kchunk = (s.B + 31) / 32 * 32;
     g.adam = ov_adam_from(opt);
-    g.dbg = (c->flags >> 16) & 7;
+    g.dbg = OV_DBG((c->flags >> 16) & 7);
     OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
     const bool resident = (s.ldb % 4 == 0) && ov_al16(g.A) && (int64_t)d.L * d.G * 4 < ((int64_t)1 << 31) &&
-                          !((c->flags >> 22) & 1);
+                          !OV_DBG((c->flags >> 22) & 1);
     if (apply) {
         g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
         if (resident) return ov_launch_dw0<OV_EPI_ADAMW>(g, s.st);
-        const int var = (c->flags >> 12) & 3;
+        const int var = OV_DBG((c->flags >> 12) & 3);
         const bool al = (d.G % 4 == 0) && ov_al16(g.C) && ov_al16(g.Pm) && ov_al16(g.Pv);
-        if (al && ov_al16(g.B) && ((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_ADAMW>(g, 1, s.st);
+        if (al && ov_al16(g.B) && OV_DBG((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_ADAMW>(g, 1, s.st);
         if (!al || var == 0) return ov_launch_gemm<1, 1, 1, 4, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
         if (var == 1) return ov_launch_gemm<1, 2, 1, 2, true, false, OV_EPI_ADAMW>(g, 1, true, s.st);
         if (var == 2) return ov_launch_gemm<1, 2, 1, 2, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
@@ -2880,7 +2876,7 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     }
     g.C = c->Gr + c->lay.W0;
     if (resident) return ov_launch_dw0<OV_EPI_STORE>(g, s.st);
-    if ((d.G % 4 == 0) && ov_al16(g.B) && ((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_STORE>(g, 1, s.st);
+    if ((d.G % 4 == 0) && ov_al16(g.B) && OV_DBG((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_STORE>(g, 1, s.st);
     return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_STORE>(g, 1, true, s.st);
 }
 
@@ -2897,7 +2893,7 @@ extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, cons
     ov_make_step(ctx, x, xidx, B, stream, &s);
     s.side = ov_side_get(ctx);
     bool refreshed = false;
-    if (s.side && ov_fused_bt(ctx) != 0 && (ctx->flags & 32u)) {      // packed decoder weight copies || encoder (measurement only)
+    if (s.side && ov_fused_bt(ctx) != 0 && OV_DBG((ctx->flags & 32u) != 0)) {      // packed decoder weight copies || encoder (measurement only)
         if ((rc = ov_side_fork(s))) return rc;
         if ((rc = ov_sell_refresh(s, s.side->st))) return rc;
         refreshed = true;
