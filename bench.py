@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: train samples/sec of the GO-BP OntoVAE step (forward + backward + AdamW)
-on N MI355X, BASELINE.json configs[1]: GOBP-syn (G=20000, T=3000, K=12, nu=3), fp32, batch 128
-per GPU, synthetic data, inputs resident in HBM.
+"""Benchmarks of the OntoVAE hot path on MI355X (GOBP-syn: G=20000, T=3000, K=12, nu=3, fp32, synthetic data resident in HBM).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus 1] [--steps 200] [--warmup 20]
+        BASELINE.json configs[1]: train step (forward + backward + AdamW) at batch 128 on one GPU.  The same JSON line also
+        carries (extra keys, measured after the timed region): the inference benchmark (configs[3]), the perturbation
+        screen, and the single-GPU step at the global batch of configs[2] (8192 rows).
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+        BASELINE.json configs[2]: data-parallel training at GLOBAL batch 8192 (8192 / N rows per GPU, SyncBN + SUM
+        exchange over RCCL, onto_vae_amd/parallel.py); total work per step is fixed, so "scaling" is "strong".  Rank 0
+        first times the same global batch on its GPU alone (key single_gpu_same_global_batch): the curve's own baseline.
+    python bench.py --global-batch 8192          one GPU at configs[2]'s global batch
+    python bench.py --batch B [--gpus N]         weak scaling at B rows per GPU (round 1's multi-GPU mode)
+    python bench.py --mode infer | screen        configs[3] / the knock-out screen alone
 
-One JSON line on rank 0.  N > 1 is data parallel, weak scaling: every rank takes `--batch` rows
-of a global batch of N * batch (SyncBN + SUM all-reduce over RCCL, onto_vae_amd/parallel.py).
-`roofline` describes the dominant kernel of the step (HIP events around its launches inside the
-timed region); `cpu_baseline` is the dense CPU oracle timed on this box's host cores (N=1 only).
+One JSON line on rank 0.  `value` = rows of all ranks / max-over-ranks wall time of exactly --steps steps, bracketed by
+barrier + device synchronise.  `roofline` describes the dominant kernel of the step: its time is the mean of HIP-event
+pairs recorded by the library around that kernel's launches INSIDE the timed region, on the launch stream
+(ontovae_profile_*); `frac` = algorithmic bytes (or flops) / that time / peak.  `roofline_kernels` lists every launch of
+the step the same way (events recorded during the second half of the warm-up) with `traffic` = HBM-side bytes per launch
+from this round's rocprofv3 --pmc passes (profiles/pmc_traffic.json).  `cpu_baseline` is the dense CPU oracle timed on
+this box's host cores (N = 1 only).
 """
 import argparse
 import ctypes as C
@@ -27,26 +37,51 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+GLOBAL_BATCH = 8192          # BASELINE.json configs[2]
 
 
-def phase_cost(name, d, B, nnz_t=0):
-    """Algorithmic (bytes, flops) of one launch-set of a phase per step; None where it is not modelled.
-    nnz_t = non-zeros of the term layers (rows of the node-space operator below C)."""
+def phase_cost(name, d, B, nnz_t):
+    """Algorithmic (HBM bytes, flops) of the launch(es) of one phase of a training step; None where a phase has no launch of
+    its own.  nnz_t = non-zeros of the term layers, nnz_g of the gene layer; every array is counted once per launch that
+    must read or write it, indices as 4 bytes."""
     L, G, C_, nnz = d.L, d.G, d.C, int(d.nnz)
+    nnz_g = nnz - nnz_t
     f = 4
-    if name == "dw0":       # read dh + x, read+write w, m, v of W0 (fused AdamW); 2*L*G*B flops
-        return (6 * L * G + B * G + L * B) * f, 2.0 * L * G * B
-    if name == "enc_gemm":  # read W0 and x once, write h
-        return (L * G + B * G + L * B) * f, 2.0 * L * G * B
-    if name == "dec_wgrad":  # per non-zero: w, m, v read+write, index; D and ACT rows once
-        return (6 * nnz + nnz + (2 * C_ + G) * B) * f, 2.0 * nnz * B
-    if name == "dec_fwd_gene":
-        return (2 * nnz + C_ * B + 2 * G * B) * f, 2.0 * nnz * B
-    if name == "dec_bwd_gene":   # gene-layer links: value + row index + k; D gene rows read, D panel rows written
-        return (3 * (nnz - nnz_t) + (C_ + G) * B) * f, 2.0 * (nnz - nnz_t) * B
-    if name == "dec_bwd":        # term levels: packed link records once per 4-column panel pass, D panel read + written
-        return (2 * nnz_t * (B // 4) + 2 * C_ * B) * f, 2.0 * nnz_t * B
-    return None
+    cost = {
+        "enc_gemm": ((L * G + B * G + L * B) * f, 2.0 * L * G * B),                 # W0, x once, h out
+        "bn_fwd": (3 * L * B * f, 10.0 * L * B),                                    # h in, xhat + a out
+        "heads": ((2 * L * L + L * B + 2 * L * B) * f, 4.0 * L * L * B),
+        "reparam": (6 * L * B * f, 12.0 * L * B),                                   # mu, log_var, eps in; z, eps copy, mu/lv out
+        "dec_fwd_terms": ((2 * nnz_t + L * B + C_ * B) * f, 2.0 * nnz_t * B),       # links, z in, panel out
+        "dec_fwd_gene": ((2 * nnz_g + C_ * B + 2 * G * B) * f, 2.0 * nnz_g * B),    # links, panel in, x in, dL/drecon out
+        "dec_bwd_gene": ((3 * nnz_g + (C_ + G) * B) * f, 2.0 * nnz_g * B),          # links (row, k, w), D genes in, D panel out
+        # backward term chain + (riders) weight-gradient partials of 75 % of the gene rows
+        "dec_bwd": ((2 * nnz_t + 2 * C_ * B + (G + C_) * B + int(0.75 * nnz_g) * (1 + max(B // 32, 1))) * f,
+                    2.0 * nnz_t * B + 1.5 * nnz_g * B),
+        # d mu / d log_var + (riders) partials of the term rows and the other 25 % of the gene rows
+        "latent_bwd": ((6 * L * B + (G + C_) * B // 4 + (nnz_t + nnz_g // 4) * (1 + max(B // 32, 1))) * f,
+                       16.0 * L * B + 2.0 * (nnz_t + 0.25 * nnz_g) * B),
+        # da = Wh^T [dmu; dlv] + (riders) decoder finish pass: partial sums, AdamW on w, m, v, clamp
+        "da_gemm": ((2 * L * L + 3 * L * B + nnz * (max(B // 32, 1) + 6)) * f, 4.0 * L * L * B + 12.0 * nnz),
+        "dwh": ((6 * 2 * L * L + 3 * L * B + 4 * L * B) * f, 4.0 * L * L * B),      # dWh + AdamW, BatchNorm backward
+        "dw0": ((6 * L * G + B * G + L * B) * f, 2.0 * L * G * B),                  # w, m, v read + written, x, dh
+    }
+    return cost.get(name)
+
+
+def roofline_entry(name, ms, d, B, nnz_t, traffic):
+    cost = phase_cost(name, d, B, nnz_t)
+    if cost is None or ms <= 0:
+        return None
+    nbytes, flops = cost
+    sec = ms * 1e-3
+    t_hbm, t_mfma = nbytes / (PEAK_HBM_GBS * 1e9), flops / (PEAK_F32_MFMA_TF * 1e12)
+    mfma_kernel = name in ("enc_gemm", "heads", "da_gemm", "dwh", "dw0")
+    bound = "mfma" if (mfma_kernel and t_mfma > t_hbm) else "hbm"
+    e = {"kernel": name, "us": round(ms * 1e3, 2), "bound": bound, "algorithmic_bytes": int(nbytes), "algorithmic_flops": flops,
+         "GBps": round(nbytes / sec / 1e9, 1), "TFLOPs": round(flops / sec / 1e12, 2),
+         "frac": round((t_mfma if bound == "mfma" else t_hbm) / sec, 4), "traffic": traffic.get(name)}
+    return e
 
 
 def build_model(device):
@@ -104,13 +139,41 @@ def cpu_baseline(masks, B, budget_s=20.0):
                       f"dense numpy oracle (oracle/ontovae_oracle.py) on {use} threads"}
 
 
-def infer_bench(a, model, dev, world, rank):
+def _pmc_traffic():
+    """HBM-side bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), {} if absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return {}
+
+
+def _timed(fn, steps, world, dev):
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def infer_bench(a, model, dev, world, rank, steps=None, warmup=None):
     """Inference throughput: every rank streams its own rows (no collective), activities written to a resident
     [rows, T] output; the kernels are the eval-mode encoder, the term chain and the nu-mean (no gene layer)."""
-    import torch.distributed as dist
     e = model._engine
     d = e.plan.dims
-    B = a.batch if a.batch != 128 else 16384          # 5.56 / 5.73 / 5.84 M samples/s at 4096 / 8192 / 16384 rows per batch
+    steps = a.steps if steps is None else steps
+    warmup = a.warmup if warmup is None else warmup
+    B = a.batch if a.batch not in (None, 128) else 16384          # 5.56 / 5.73 / 5.84 M samples/s at 4096 / 8192 / 16384 rows per batch
     rows = max(a.rows // B, 1) * B
     model.eval()
     X = synth_X(rows, d.G, dev, seed=1234 + rank)
@@ -123,61 +186,39 @@ def infer_bench(a, model, dev, world, rank):
         e.pass_data(X[i * B:(i + 1) * B], None, None, None, act_out=out[i * B:(i + 1) * B])
         it[0] += 1
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = _timed(step, steps, world, dev)
     assert torch.isfinite(out[:B]).all()
-    if rank == 0:
-        value = B * world * a.steps / dt
-        # per sample: encoder 2 G L + heads 4 L^2 flops (MFMA-bound); 4 G bytes in, 4 T out
-        flops = (2.0 * d.G * d.L + 4.0 * d.L * d.L) * B
-        t_mfma = flops / (PEAK_F32_MFMA_TF * 1e12)
-        sec = dt / a.steps
-        print(json.dumps({
-            "metric": "inference samples/sec (GO-BP OntoVAE get_pathway_activities)", "value": value, "unit": "samples/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[3]: GOBP-syn get_pathway_activities ('act' output, [rows, 3000] fp32), "
-                                   f"batches of {B} rows from {rows} HBM-resident rows per GPU", "batch_per_gpu": B,
-                       "dataset_rows": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                         "frac": t_mfma / sec, "traffic": None, "kernel": "whole step (encoder GEMM dominates)",
-                         "algorithmic_flops": flops}}))
-    if world > 1:
-        dist.destroy_process_group()
+    value = B * world * steps / dt
+    # per sample: encoder 2 G L + heads 4 L^2 flops (MFMA-bound); 4 G bytes in, 4 T out
+    flops = (2.0 * d.G * d.L + 4.0 * d.L * d.L) * B
+    t_mfma = flops / (PEAK_F32_MFMA_TF * 1e12)
+    sec = dt / steps
+    del X, out
+    return {
+        "metric": "inference samples/sec (GO-BP OntoVAE get_pathway_activities)", "value": value, "unit": "samples/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[3]: GOBP-syn get_pathway_activities ('act' output, [rows, 3000] fp32), "
+                               f"batches of {B} rows from {rows} HBM-resident rows per GPU", "batch_per_gpu": B,
+                   "dataset_rows": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
+        "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                     "frac": t_mfma / sec, "traffic": None, "kernel": "whole step (encoder GEMM dominates)",
+                     "algorithmic_flops": flops}}
 
 
-def _pmc_traffic(key):
-    """HBM-side bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), or None."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
-    except Exception:
-        return None
-
-
-def screen_bench(a, model, dev, world, rank):
+def screen_bench(a, model, dev, world, rank, steps=None, warmup=None):
     """In-silico knock-out screen: a step is ONE single-gene perturbation of N resident samples:
     the perturbed pass from the cached first layer (ontovae_pass_data_perturbed), the move to feature-major, and the
     paired Wilcoxon test of all T terms against the control activities; the Benjamini-Hochberg pass over all steps'
     p-values closes the timed region, as OntoVAE.perturbation_screen does.  Ranks screen disjoint gene ranges."""
-    import torch.distributed as dist
     from onto_vae_amd import stats as dstats
     e = model._engine
     d = e.plan.dims
-    N = a.batch if a.batch != 128 else 4096
+    steps = a.steps if steps is None else steps
+    warmup = a.warmup if warmup is None else warmup
+    N = a.batch if a.batch not in (None, 128) else 4096
     model.eval()
     X = synth_X(N, d.G, dev, seed=77)
     T = e.plan.T
@@ -189,11 +230,12 @@ def screen_bench(a, model, dev, world, rank):
     e.encode_pre(X, None, hpre, 0)
     e.pass_data_perturbed(X, None, hpre, 0, none_g, none_v, None, None, act_out=stage)
     dstats.to_feature_major(stage, ctrl)
-    P = a.warmup + a.steps
+    P = warmup + steps
     stat = torch.empty(P, T, dtype=torch.float64, device=dev)
     pval = torch.empty(P, T, dtype=torch.float64, device=dev)
     zero = np.zeros(1, np.float32)
     it = [0]
+    q = [None]
 
     def step(full=False):
         i = it[0]
@@ -203,40 +245,27 @@ def screen_bench(a, model, dev, world, rank):
             X[:, g] = 0.0
             e.pass_data(X, None, None, None, act_out=stage)
             X[:, g] = col
+            dstats.to_feature_major(stage, pert)
         else:
             e.pass_data_perturbed(X, None, hpre, 0, np.array([g], np.int32), zero, None, None, act_fm=pert)
-        if full:
-            dstats.to_feature_major(stage, pert)
         dstats.wilcoxon_zsplit(pert, ctrl, N, "greater", out=(stat[i % P], pval[i % P]))
         it[0] += 1
 
-    def timed(n, full):
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(n):
+    def run(n, full):
+        def body():
             step(full)
-        q = dstats.fdr_bh(pval[:max(n, 1)])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, q
+            if it[0] == n:
+                q[0] = dstats.fdr_bh(pval[:max(n, 1)])
+        it[0] = 0
+        return _timed(body, n, world, dev)
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
-    it[0] = 0
-    dt, q = timed(a.steps, False)
-    assert torch.isfinite(q).all() and torch.isfinite(stat[:a.steps]).all()
-    it[0] = 0
-    nfull = max(min(a.steps // 4, 50), 1)
+    dt = run(steps, False)
+    assert torch.isfinite(q[0]).all() and torch.isfinite(stat[:steps]).all()
+    nfull = max(min(steps // 4, 50), 1)
     step(True)
-    dt_full, _ = timed(nfull, True)
+    dt_full = run(nfull, True)
     # Wilcoxon kernel alone, under events on the launch stream
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
@@ -245,25 +274,83 @@ def screen_bench(a, model, dev, world, rank):
     ev[1].record()
     torch.cuda.synchronize()
     wx_ms = ev[0].elapsed_time(ev[1]) / 10
-    if rank == 0:
-        sec = dt / a.steps
-        # the Wilcoxon kernel reads both [T, N] matrices once: 8 N T bytes
-        wx_bytes = 8.0 * N * T
-        print(json.dumps({
-            "metric": "perturbations/sec (GO-BP single-gene knock-out screen: perturbed pass + paired Wilcoxon of all terms + FDR)",
-            "value": world * a.steps / dt, "unit": "perturbations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"GOBP-syn, {N} HBM-resident samples, one knocked-out gene per step, {T} terms tested per step, "
-                                   "Benjamini-Hochberg over all steps at the end", "samples": N,
-                       "parallelism": f"dp{world}" if world > 1 else "single",
-                       "full_pass_ms_per_step": dt_full / nfull * 1e3, "wilcoxon_kernel_ms": wx_ms},
-            "roofline": {"bound": "hbm", "achieved": wx_bytes / (wx_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": wx_bytes / (wx_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _pmc_traffic("wilcoxon"),
-                         "kernel": "ov_wilcoxon_sort_kernel (bitonic sort in registers: bound by its vector instructions, not HBM)",
-                         "algorithmic_bytes": wx_bytes}}))
-    if world > 1:
-        dist.destroy_process_group()
+    sec = dt / steps
+    wx_bytes = 8.0 * N * T          # the Wilcoxon kernel reads both [T, N] matrices once
+    return {
+        "metric": "perturbations/sec (GO-BP single-gene knock-out screen: perturbed pass + paired Wilcoxon of all terms + FDR)",
+        "value": world * steps / dt, "unit": "perturbations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"GOBP-syn, {N} HBM-resident samples, one knocked-out gene per step, {T} terms tested per step, "
+                               "Benjamini-Hochberg over all steps at the end", "samples": N,
+                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "full_pass_ms_per_step": dt_full / nfull * 1e3, "wilcoxon_kernel_ms": wx_ms},
+        "roofline": {"bound": "hbm", "achieved": wx_bytes / (wx_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": wx_bytes / (wx_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _pmc_traffic().get("wilcoxon"),
+                     "kernel": "ov_wilcoxon_sort_kernel (bitonic sort in registers: bound by its vector instructions, not HBM)",
+                     "algorithmic_bytes": wx_bytes}}
+
+
+def train_bench(model, dev, world, rank, B, steps, warmup, rows, profile=True, single=False):
+    """`steps` training steps at B rows per rank (global batch B * world; single=True: this rank alone, no collectives).
+    Returns (seconds of the timed region [max over ranks], per-phase ms per step, dominant phase, its ms per step inside
+    the timed region, its launches per step, final loss)."""
+    from onto_vae_amd import _lib
+    from onto_vae_amd.vae_model import FusedAdamW
+    from onto_vae_amd.parallel import dp_train_step
+    e = model._engine
+    d = e.plan.dims
+    w = 1 if single else world
+    Bg = B * w
+    rows = max(rows, Bg)
+    X = synth_X(rows, d.G, dev)
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(1)).to(dev).to(torch.int32)
+    nb = rows // Bg
+    opt = FusedAdamW(model, lr=1e-4)
+    kc = 1e-4
+    loss = torch.zeros(warmup + steps + 64, 3, device=dev)
+    L = _lib.lib()
+    it = [0]
+
+    def step():
+        i = it[0]
+        idx = perm[(i % nb) * Bg:(i % nb + 1) * Bg]
+        if w > 1:
+            dp_train_step(model, X, idx, None, kc, opt, loss[i % loss.shape[0]], reduce_loss=False)
+        else:
+            e.train_step(X, idx, None, kc, opt.next_hyper(), loss[i % loss.shape[0]])
+        it[0] += 1
+
+    nprobe = min(10, max(warmup // 2, 1))
+    for _ in range(warmup - nprobe):
+        step()
+    phase_ms, dom, dom_ms_step, launches = {}, None, 0.0, 0
+    cnt = C.c_int32()
+    if profile:
+        # the second part of the warm-up runs with every phase under HIP events: per-kernel times and the dominant phase
+        nph = len(_lib.PHASES)
+        _lib.check(L.ontovae_profile_begin((1 << nph) - 1, 64 * nprobe), "profile_begin")
+    for _ in range(nprobe):
+        step()
+    torch.cuda.synchronize()
+    if profile:
+        buf = (C.c_float * (64 * nprobe))()
+        for ph, name in enumerate(_lib.PHASES):
+            _lib.check(L.ontovae_profile_read(ph, buf, 64 * nprobe, C.byref(cnt)), "profile_read")
+            phase_ms[name] = sum(buf[i] for i in range(cnt.value)) / nprobe
+        dom = max(phase_ms, key=phase_ms.get)
+        _lib.check(L.ontovae_profile_begin(1 << _lib.PHASES.index(dom), 16 * steps), "profile_begin")
+    dt = _timed(step, steps, w, dev)
+    if profile:
+        kbuf = (C.c_float * (16 * steps))()
+        _lib.check(L.ontovae_profile_read(_lib.PHASES.index(dom), kbuf, 16 * steps, C.byref(cnt)), "profile_read")
+        launches = cnt.value
+        dom_ms_step = sum(kbuf[i] for i in range(launches)) / steps
+        L.ontovae_profile_end()
+    final = loss[:min(it[0], loss.shape[0])].cpu().numpy()
+    assert np.isfinite(final).all(), "non-finite loss in the benchmark run"
+    del X
+    return dt, phase_ms, dom, dom_ms_step, launches / max(steps, 1), float(final[-1, 2])
 
 
 def main():
@@ -271,9 +358,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=128, help="rows per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default: 128 on one GPU, 8192 / N on N)")
+    ap.add_argument("--global-batch", type=int, default=None, help="global batch (one GPU: the whole batch on it)")
     ap.add_argument("--rows", type=int, default=65536, help="synthetic dataset rows resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="train mode, one GPU: skip the inference / screen / global-batch legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-phase times to stderr")
     ap.add_argument("--mode", choices=["train", "infer", "screen"], default="train",
                     help="infer: BASELINE.json configs[3], get_pathway_activities-equivalent (ontovae_pass_data, 'act' output) over "
@@ -295,120 +384,102 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from onto_vae_amd import _lib
-    from onto_vae_amd.vae_model import FusedAdamW
-    from onto_vae_amd.parallel import dp_train_step
     model, masks = build_model(dev)
     e = model._engine
     d = e.plan.dims
-    if a.mode == "infer":
-        return infer_bench(a, model, dev, world, rank)
-    if a.mode == "screen":
-        return screen_bench(a, model, dev, world, rank)
-    B = a.batch
-    Bg = B * world
-    X = synth_X(a.rows, d.G, dev)
-    perm = torch.randperm(a.rows, generator=torch.Generator().manual_seed(1)).to(dev).to(torch.int32)
-    nb = a.rows // Bg
-    opt = FusedAdamW(model, lr=1e-4)
-    kc = 1e-4
-    loss = torch.zeros(a.warmup + a.steps + 64, 3, device=dev)
-    L = _lib.lib()
-    it = [0]
-
-    def step():
-        i = it[0]
-        idx = perm[(i % nb) * Bg:(i % nb + 1) * Bg]
+    if a.mode in ("infer", "screen"):
+        res = (infer_bench if a.mode == "infer" else screen_bench)(a, model, dev, world, rank)
+        if rank == 0:
+            print(json.dumps(res))
         if world > 1:
-            dp_train_step(model, X, idx, None, kc, opt, loss[i % loss.shape[0]], reduce_loss=False)
-        else:
-            e.train_step(X, idx, None, kc, opt.next_hyper(), loss[i % loss.shape[0]])
-        it[0] += 1
+            dist.destroy_process_group()
+        return
 
-    # warm-up; its first part also finds the dominant phase with all phases under HIP events
-    nprobe = min(10, max(a.warmup // 2, 1))
-    for _ in range(a.warmup - nprobe):
-        step()
-    nph = len(_lib.PHASES)
-    _lib.check(L.ontovae_profile_begin((1 << nph) - 1, 64 * nprobe), "profile_begin")
-    for _ in range(nprobe):
-        step()
-    torch.cuda.synchronize()
-    buf = (C.c_float * (64 * nprobe))()
-    cnt = C.c_int32()
-    phase_ms = {}
-    for ph, name in enumerate(_lib.PHASES):
-        _lib.check(L.ontovae_profile_read(ph, buf, 64 * nprobe, C.byref(cnt)), "profile_read")
-        phase_ms[name] = sum(buf[i] for i in range(cnt.value)) / nprobe
-    dom = max(phase_ms, key=phase_ms.get)
+    # which workload: configs[1] on one GPU, configs[2] on several (or with --global-batch), --batch overrides both
+    if a.batch is not None:
+        B, scaling = a.batch, "weak"
+        workload = (f"GOBP-syn OntoVAE fp32 train step, {B} rows per GPU (weak scaling)" if (world > 1 or B != 128) else None)
+    elif a.global_batch is not None or world > 1:
+        gb = a.global_batch or GLOBAL_BATCH
+        if gb % world:
+            raise SystemExit(f"global batch {gb} is not a multiple of {world} ranks")
+        B, scaling = gb // world, "strong"
+        workload = (f"BASELINE.json configs[2]: GOBP-syn OntoVAE (G=20000, T=3000, K=12, nu=3, L=360) fp32 data-parallel train "
+                    f"step, global batch {gb} = {world} x {B} rows, SyncBN + SUM gradient exchange, lr 1e-4, kl_coeff 1e-4, dropout off")
+    else:
+        B, scaling, workload = 128, "weak", None
+    if workload is None:
+        workload = ("BASELINE.json configs[1]: GOBP-syn OntoVAE (G=20000, T=3000, K=12, nu=3, L=360) "
+                    "fp32 train step, batch 128 per GPU, lr 1e-4, kl_coeff 1e-4, dropout off")
+    Bg = B * world
+    nnz_t = int(e.plan.rowptr[d.C])
+
+    single_same = None
+    if world > 1 and scaling == "strong":
+        # the curve's own baseline: the same global batch on ONE GPU (rank 0 alone; the other ranks wait at the barrier)
+        if rank == 0:
+            n1 = max(min(a.steps // 4, 50), 10)
+            dt1, *_ = train_bench(model, dev, world, rank, Bg, n1, 5, a.rows, profile=False, single=True)
+            single_same = {"value": Bg * n1 / dt1, "unit": "samples/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "n_gpus": 1,
+                           "global_batch": Bg}
+        model, masks = build_model(dev)          # fresh weights and optimizer state on every rank
+        e = model._engine
+        dist.barrier()
+
+    dt, phase_ms, dom, dom_ms_step, lps, final_loss = train_bench(model, dev, world, rank, B, a.steps, a.warmup, a.rows)
     if a.breakdown and rank == 0:
         print("per-phase ms/step (event-bracketed, includes launch gaps):", {k: round(v, 4) for k, v in phase_ms.items()},
               "sum", round(sum(phase_ms.values()), 4), file=sys.stderr)
-    _lib.check(L.ontovae_profile_begin(1 << _lib.PHASES.index(dom), 16 * a.steps), "profile_begin")
-
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    kbuf = (C.c_float * (16 * a.steps))()
-    _lib.check(L.ontovae_profile_read(_lib.PHASES.index(dom), kbuf, 16 * a.steps, C.byref(cnt)), "profile_read")
-    launches = cnt.value
-    dom_ms_step = sum(kbuf[i] for i in range(launches)) / a.steps
-    L.ontovae_profile_end()
-    final = loss[:min(it[0], loss.shape[0])].cpu().numpy()
-    assert np.isfinite(final).all(), "non-finite loss in the benchmark run"
 
     if rank == 0:
         value = Bg * a.steps / dt
-        # data parallel: every rank forms dW0 of the GLOBAL batch (parallel.py), the other kernels see the local rows
-        cost = phase_cost(dom, d, Bg if dom == "dw0" else B, int(e.plan.rowptr[d.C]))
+        traffic = _pmc_traffic() if (B == 128 and world == 1) else {}
+        # data parallel in the gathered-dh form: every rank forms dW0 of the GLOBAL batch (parallel.py)
+        from onto_vae_amd.parallel import use_gathered_dh
+        dw0_rows = Bg if (world > 1 and use_gathered_dh(Bg, world, d.L, d.G)) else B
+        rows_of = lambda name: dw0_rows if name == "dw0" else B
+        kernels = [r for r in (roofline_entry(n, ms, d, rows_of(n), nnz_t, traffic) for n, ms in phase_ms.items()) if r]
         roof = None
-        if cost is not None:
-            nbytes, flops = cost
-            t_hbm = nbytes / (PEAK_HBM_GBS * 1e9)
-            t_mfma = flops / (PEAK_F32_MFMA_TF * 1e12)
-            sec = dom_ms_step * 1e-3
-            if t_hbm >= t_mfma:
-                ach = nbytes / sec / 1e9
-                roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
-            else:
-                ach = flops / sec / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TF}
-            roof.update({"traffic": None, "kernel": dom, "kernel_ms_per_step": dom_ms_step, "launches_per_step": launches / a.steps,
-                         "algorithmic_bytes": nbytes, "algorithmic_flops": flops})
-            tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tr):
-                try:
-                    roof["traffic"] = json.load(open(tr)).get(dom)
-                except Exception:
-                    pass
+        domr = roofline_entry(dom, dom_ms_step, d, rows_of(dom), nnz_t, traffic)
+        if domr is not None:
+            unit = "TFLOP/s" if domr["bound"] == "mfma" else "GB/s"
+            ach = domr["TFLOPs"] if domr["bound"] == "mfma" else domr["GBps"]
+            roof = {"bound": domr["bound"], "achieved": ach, "peak": PEAK_F32_MFMA_TF if domr["bound"] == "mfma" else PEAK_HBM_GBS,
+                    "unit": unit, "frac": domr["frac"], "traffic": domr["traffic"], "kernel": dom,
+                    "kernel_ms_per_step": dom_ms_step, "launches_per_step": lps, "timer": "HIP events on the launch stream, inside the timed region",
+                    "algorithmic_bytes": domr["algorithmic_bytes"], "algorithmic_flops": domr["algorithmic_flops"]}
         # whole-step roofline of BASELINE.md: max(F_s*B / mfma, (40 P + 4 G B) / hbm) / t_step
         P_real = d.L * d.G + 2 * d.L * d.L + int(d.nnz) + 6 * d.L + (d.C - d.L) + d.G
         t_bound = max((2.0 * 2 * d.L * d.G + 3 * 4.0 * d.L * d.L + 3 * 2.0 * int(d.nnz)) * B / (PEAK_F32_MFMA_TF * 1e12),
                       (40.0 * P_real + 4.0 * d.G * B) / (PEAK_HBM_GBS * 1e9))
         out = {"metric": "train samples/sec (GO-BP OntoVAE fwd+bwd+step)", "value": value, "unit": "samples/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BASELINE.json configs[1]: GOBP-syn OntoVAE (G=20000, T=3000, K=12, nu=3, L=360) "
-                                      "fp32 train step, batch 128 per GPU, lr 1e-4, kl_coeff 1e-4, dropout off",
-                          "batch_per_gpu": B, "global_batch": Bg, "dataset_rows": a.rows,
+               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": workload, "batch_per_gpu": B, "global_batch": Bg, "dataset_rows": max(a.rows, Bg),
                           "parallelism": f"dp{world}" if world > 1 else "single"},
                "roofline": roof, "step_roofline_frac": t_bound / (dt / a.steps),
+               "roofline_kernels": kernels,
                "phase_ms_per_step": {k: round(v, 5) for k, v in phase_ms.items()},
-               "final_loss": float(final[-1, 2])}
+               "final_loss": final_loss}
+        if single_same is not None:
+            out["single_gpu_same_global_batch"] = single_same
+        if world == 1 and not a.no_extras and B == 128 and a.global_batch is None:
+            # the other headline workloads, measured after the timed region so that the driver's run covers them too
+            xa = argparse.Namespace(**vars(a))
+            xa.batch, xa.rows = None, 65536
+            inf = infer_bench(xa, model, dev, 1, 0, steps=20, warmup=3)
+            out["inference"] = {k: inf[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline")}
+            scr = screen_bench(xa, model, dev, 1, 0, steps=100, warmup=10)
+            out["screen"] = {k: scr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline")}
+            m2, _ = build_model(dev)
+            n1 = 30
+            dt1, ph1, *_ = train_bench(m2, dev, 1, 0, GLOBAL_BATCH, n1, 6, a.rows)
+            out["global_batch_8192_single_gpu"] = {
+                "metric": "train samples/sec at configs[2]'s global batch on one GPU", "value": GLOBAL_BATCH * n1 / dt1,
+                "unit": "samples/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1,
+                "roofline_kernels": [r for r in (roofline_entry(n, ms, d, GLOBAL_BATCH, nnz_t, {}) for n, ms in ph1.items()) if r]}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(masks, B)
+            out["cpu_baseline"] = cpu_baseline(masks, 128)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -246,6 +246,14 @@ int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, const float* 
                           float kl_coeff, float* bn_stats, float* bn_bwd_stats, float* loss_out,
                           void* stream);
 
+/* Phase 3 of ontovae_train_step_dp is phase 2 without the dW0 product (BatchNorm backward only); ontovae_dw0_rows then
+ * forms rows [l0, l1) of dW0 = dh x (the local rows' contribution) into ctx->Gr, so that the caller can all-reduce W0's
+ * gradient in contiguous row panels, each panel's exchange under the next panel's product (SURVEY.md 8(e) bucket 3; row
+ * panels instead of gene-column panels because rows are contiguous in the flat buffer).  No counterpart in the
+ * reference (single device). */
+int ontovae_dw0_rows(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, int32_t l0, int32_t l1,
+                     void* stream);
+
 /* torch.optim.AdamW.step over the flat buffers (vae_model.py:172) + clamp(0) of the packed
  * decoder weights (vae_model.py:175-176), reading gradients from ctx->Gr. */
 int ontovae_adamw_apply(const ontovae_ctx_t* ctx, const ontovae_adamw_t* opt, void* stream);

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ONTOVAE_HIP_LIB") or os.path.join(HERE, "libontovae_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -94,6 +94,7 @@ def lib():
         "ontovae_adamw_apply": [C.POINTER(Ctx), C.POINTER(AdamW), vp],
         "ontovae_adamw_apply_range": [C.POINTER(Ctx), C.POINTER(AdamW), i64, i64, vp],
         "ontovae_dp_bn_bwd": [C.POINTER(Ctx), i32, i32, vp, u64, vp, i32, vp],
+        "ontovae_dw0_rows": [C.POINTER(Ctx), vp, vp, i32, i32, i32, vp],
         "ontovae_dw0_global": [C.POINTER(Ctx), vp, vp, vp, i32, i32, vp, i64, C.POINTER(AdamW), i32, vp],
         "ontovae_dp_pack_dy": [C.POINTER(Ctx), i32, vp, i32, vp],
         "ontovae_dp_dh_global": [C.POINTER(Ctx), i32, i32, c_i32p, i32, vp, i64, vp],
@@ -133,7 +134,7 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_plan_destroy", "ontovae_plan_dims", "ontovae_plan_levels", "ontovae_plan_export",
             "ontovae_plan_entry_coords", "ontovae_plan_csc_split", "ontovae_plan_sell_sizes", "ontovae_plan_sell_export", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
             "ontovae_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
-            "ontovae_adamw_apply", "ontovae_adamw_apply_range", "ontovae_dp_bn_bwd", "ontovae_dw0_global", "ontovae_dp_pack_dy", "ontovae_dp_dh_global", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
+            "ontovae_adamw_apply", "ontovae_adamw_apply_range", "ontovae_dp_bn_bwd", "ontovae_dw0_rows", "ontovae_dw0_global", "ontovae_dp_pack_dy", "ontovae_dp_dh_global", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
             "ontovae_encode_pre", "ontovae_pass_data_perturbed",
             "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals",
             "ontovae_wilcoxon_workspace_bytes", "ontovae_wilcoxon_zsplit", "ontovae_fdr_workspace_bytes", "ontovae_fdr_bh", "ontovae_fdr_bh_static",

@@ -97,7 +97,16 @@ extern "C" int ontovae_profile_read(int32_t phase, float* ms, int32_t cap, int32
 }
 
 static inline int ov_vec(int B) { return B <= 64 ? 1 : (B <= 128 ? 2 : 4); }
-static inline int ov_ldb(int B) { const int q = 64 * ov_vec(B); return (B + q - 1) / q * q; }
+static inline int ov_ldb(int B) {
+    const int q = 64 * ov_vec(B);
+    int ldb = (B + q - 1) / q * q;
+    // Large batches: an odd multiple of 256 floats, so that the rows of a feature-major matrix do not sit a power of two
+    // apart.  A 32-column block reads one 128-B line of every row; at a row stride of 16 or 32 KB those lines fell on a
+    // few memory channels and the gene layer ran 1.7x slower per column at 8192 columns than at 128 (measured: forward
+    // gene layer 2250 -> 1290 us at B = 8192, whole step 9.8 -> 8.5 ms).  At most 6 % of padding columns.
+    if (ldb >= 4096 && ((ldb >> 8) & 1) == 0) ldb += 256;
+    return ldb;
+}
 
 // =================================================================================================
 // Workspace
@@ -1178,7 +1187,7 @@ __global__ __launch_bounds__(512) void ov_dec_gene_tile_kernel(const int32_t* __
 #endif
 struct OvCbMap { int cb, tile; };
 // workgroup id -> (column block, row tile); ncb is 1, 2, 4, 8 or a multiple of 8
-__device__ __forceinline__ OvCbMap ov_cb_map(int id, int ncb) {
+__device__ __forceinline__ OvCbMap ov_cb_map(int id, int ncb, int ntiles) {
     const int xcd = id & 7, q = id >> 3;
     OvCbMap m;
     if (ncb <= 8) {
@@ -1186,9 +1195,11 @@ __device__ __forceinline__ OvCbMap ov_cb_map(int id, int ncb) {
         m.cb = xcd % ncb;
         m.tile = q * xpc + xcd / ncb;
     } else {
-        const int cpx = ncb >> 3;             // column blocks per XCD
-        m.cb = xcd + 8 * (q % cpx);
-        m.tile = q / cpx;
+        // several column blocks per XCD, one after the other (block-major): at any time an XCD's L2 holds the rows of ONE
+        // block (1.15 MB of panel, 2.5 MB of D at GO-BP scale), whatever the batch size.  Tile-major order made the
+        // working set grow with the batch (4.6 MB at 1024 columns, 37 MB at 8192) and the gathers run at fabric pace.
+        m.cb = xcd + 8 * (q / ntiles);
+        m.tile = q % ntiles;
     }
     return m;
 }
@@ -1335,7 +1346,7 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
     __shared__ float xs[TG * LD];
     __shared__ float red[4];
     __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
-    const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
+    const OvCbMap map = ov_cb_map(blockIdx.x, ncb, ntiles);
     if (map.tile >= ntiles) {                      // workgroup-uniform
         if (MODE == 1 && threadIdx.x == 0) rec_part[blockIdx.x] = 0.f;
         return;
@@ -1410,7 +1421,7 @@ __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __re
                                                             const float* __restrict__ vals, float* __restrict__ d,
                                                             float* __restrict__ dblk, int C, int ldb, int ncb, int ntiles) {
     __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
-    const OvCbMap map = ov_cb_map(blockIdx.x, ncb);
+    const OvCbMap map = ov_cb_map(blockIdx.x, ncb, ntiles);
     if (map.tile >= ntiles) return;
     const int lane = ov_lane();
     const int col0 = map.cb * 32, s4 = 4 * (lane & 7);
@@ -1487,7 +1498,7 @@ struct OvWgradArgs {
 // wg: virtual workgroup number of the 256-thread team, tid: thread number inside the team.  Every thread of the
 // real workgroup must call this (one workgroup barrier pair inside).
 __device__ __forceinline__ void ov_wgrad_cb_body(const OvWgradArgs& a, int wg, int tid, int* sh_k0, int* sh_len, int* sh_ord) {
-    const OvCbMap map = ov_cb_map(wg, a.ncb);
+    const OvCbMap map = ov_cb_map(wg, a.ncb, a.ntiles);
     const bool tile_on = map.tile < a.ntiles;
     const int lane = ov_lane();
     const int s = lane & 7;
@@ -2849,12 +2860,16 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
 }
 
 // dW0 = dh x (+ AdamW)   (gradient of modules.py:46)
-static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
+// rows [l0, l1) of W0 only (l1 < 0: all): the data-parallel all-reduce form walks W0 in row panels, each panel's exchange
+// running under the next panel's product
+static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply, int l0 = 0, int l1 = -1) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
+    if (l1 < 0) l1 = d.L;
+    const int64_t roff = (int64_t)l0 * d.G;
     OvGemm g{};
-    g.M = d.L; g.N = d.G; g.K = s.B;
-    g.A = s.ws.dh; g.lda = s.ldb;
+    g.M = l1 - l0; g.N = d.G; g.K = s.B;
+    g.A = s.ws.dh + (int64_t)l0 * s.ldb; g.lda = s.ldb;
     g.B = s.x; g.ldb = s.xld; g.bgather = s.xidx;     // B(k=b, n=g) = X[row(b) * G + g]
     g.ldc = d.G; g.kchunk = (s.B + 31) / 32 * 32;
     g.adam = ov_adam_from(opt);
@@ -2863,7 +2878,7 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
     const bool resident = (s.ldb % 4 == 0) && ov_al16(g.A) && (int64_t)d.L * d.G * 4 < ((int64_t)1 << 31) &&
                           !OV_DBG((c->flags >> 22) & 1);
     if (apply) {
-        g.C = c->P + c->lay.W0; g.Pm = c->M + c->lay.W0; g.Pv = c->V + c->lay.W0;
+        g.C = c->P + c->lay.W0 + roff; g.Pm = c->M + c->lay.W0 + roff; g.Pv = c->V + c->lay.W0 + roff;
         if (resident) return ov_launch_dw0<OV_EPI_ADAMW>(g, s.st);
         const int var = OV_DBG((c->flags >> 12) & 3);
         const bool al = (d.G % 4 == 0) && ov_al16(g.C) && ov_al16(g.Pm) && ov_al16(g.Pv);
@@ -2874,7 +2889,7 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply) {
         if (var == 3) return ov_launch_gemm<1, 4, 1, 1, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
         return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_ADAMW_T>(g, 1, true, s.st);
     }
-    g.C = c->Gr + c->lay.W0;
+    g.C = c->Gr + c->lay.W0 + roff;
     if (resident) return ov_launch_dw0<OV_EPI_STORE>(g, s.st);
     if ((d.G % 4 == 0) && ov_al16(g.B) && OV_DBG((c->flags >> 21) & 1)) return ov_launch_gemm_lds<4, 1, false, OV_EPI_STORE>(g, 1, s.st);
     return ov_launch_gemm<1, 4, 1, 2, true, false, OV_EPI_STORE>(g, 1, true, s.st);
@@ -2927,7 +2942,7 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
         s.side = ov_side_get(ctx);
         if ((rc = ov_train_tail_a(s, eps, rng_offset, kl_coeff, nullptr, 0, loss_out, 2, bn_bwd_stats, B_global, false))) return rc;
         return ov_side_join(s);
-    } else if (phase == 2) {
+    } else if (phase == 2 || phase == 3) {
         const ontovae_dims_t& d = ctx->dims;
         const ontovae_layout_t& lay = ctx->lay;
         OvAdam adam{};
@@ -2937,10 +2952,22 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
                              ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0, nullptr, 0};
         hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, bn);
         OV_LAUNCH_CHECK();
+        if (phase == 3) return ONTOVAE_OK;          // dW0 follows in row panels (ontovae_dw0_rows)
         return ov_dw0(s, nullptr, 0);
     }
-    ontovae_set_error("train_step_dp: phase %d not in {0,1,2}", phase);
+    ontovae_set_error("train_step_dp: phase %d not in {0,1,2,3}", phase);
     return ONTOVAE_EINVAL;
+}
+
+extern "C" int ontovae_dw0_rows(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, int32_t l0, int32_t l1,
+                                void* stream) {
+    int rc = ov_check_ctx(ctx, B, false);
+    if (rc) return rc;
+    if (!x || !ctx->Gr) { ontovae_set_error("dw0_rows: x or the gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+    if (l0 < 0 || l1 > ctx->dims.L || l0 >= l1) { ontovae_set_error("dw0_rows: rows [%d, %d) outside [0, %d)", l0, l1, ctx->dims.L); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, x, xidx, B, stream, &s);
+    return ov_dw0(s, nullptr, 0, l0, l1);
 }
 
 extern "C" int ontovae_adamw_apply(const ontovae_ctx_t* ctx, const ontovae_adamw_t* opt, void* stream) {

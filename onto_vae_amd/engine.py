@@ -341,6 +341,13 @@ class Engine:
                                                 int(blm), self.stream()), "dp_bn_bwd")
 
     @_on_device
+    def dw0_rows(self, x, xidx, l0, l1):
+        """Rows [l0, l1) of dW0 = dh x of this rank's rows into Gr (after train_step_dp phase 3)."""
+        x, xidx, B = self._x(x, xidx)
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_dw0_rows(C.byref(ctx), _ptr(x), _ptr(xidx), B, int(l0), int(l1), self.stream()), "dw0_rows")
+
+    @_on_device
     def dp_pack_dy(self, B, send, blm):
         """After DP phase 1: this rank's block [dy | b0 slot | xhat | local sums] for the single all-gather."""
         ctx = self.ctx(B)

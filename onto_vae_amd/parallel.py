@@ -77,6 +77,16 @@ class _DpState:
         self.gathered2 = torch.zeros(world * self.rstride2, device=dev)
 
 
+def w0_row_panels(L, world, n_panels=None):
+    """Row ranges of W0 for the panel-wise all-reduce: n panels of (almost) equal size, multiples of 32 rows (the tile height
+    of the dW0 kernel) except the last.  ONTOVAE_DP_W0_PANELS overrides the count (1 = one all-reduce after the product)."""
+    if n_panels is None:
+        n_panels = int(os.environ.get("ONTOVAE_DP_W0_PANELS", "4"))
+    n_panels = max(1, min(n_panels, (L + 31) // 32))
+    per = ((L + n_panels - 1) // n_panels + 31) // 32 * 32
+    return [(l0, min(l0 + per, L)) for l0 in range(0, L, per)]
+
+
 def _dp_state(e, B, world, rank):
     cache = getattr(e, "_dp_cache", None)
     if cache is None:
@@ -167,12 +177,23 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
     else:
         dist.all_reduce(st.bstats, group=group)
         late, early = grad_buckets(lay)
-        h_early = dist.all_reduce(e.Gr[early[0]:early[1]], group=group, async_op=True)     # under the dW0 GEMM
-        e.train_step_dp(2, xl, il, B, el, kl_coeff, st.stats, st.bstats, lbuf, off)
-        h_late = dist.all_reduce(e.Gr[late[0]:late[1]], group=group, async_op=True)
+        h_early = dist.all_reduce(e.Gr[early[0]:early[1]], group=group, async_op=True)     # under the dW0 products
+        # W0's gradient (28.8 MB at GO-BP scale, the bulk) in contiguous ROW panels: panel p's all-reduce is issued right
+        # after its product and runs under the products of the panels after it (the collective's stream waits only for what
+        # is on the compute stream when it is issued); what stays exposed is the last panel's exchange
+        e.train_step_dp(3, xl, il, B, el, kl_coeff, st.stats, st.bstats, lbuf, off)        # BatchNorm backward -> dh, small gradients
+        G = e.plan.G
+        handles = []
+        for l0, l1 in w0_row_panels(L, world):
+            e.dw0_rows(xl, il, l0, l1)
+            handles.append((l0, l1, dist.all_reduce(e.Gr[int(lay.W0) + l0 * G:int(lay.W0) + l1 * G], group=group, async_op=True)))
+        h_small = dist.all_reduce(e.Gr[int(lay.b0):late[1]], group=group, async_op=True)   # b0, gamma, beta
+        for l0, l1, h in handles:
+            h.wait()
+            e.adamw_apply_range(hyper, int(lay.W0) + l0 * G, int(lay.W0) + l1 * G)
+        h_small.wait()
         h_early.wait()
-        h_late.wait()
-        e.adamw_apply(hyper)
+        e.adamw_apply_range(hyper, int(lay.b0), int(lay.total))
     if reduce_loss:
         dist.all_reduce(st.lloc, group=group)
         loss_out.copy_(st.lloc)
