@@ -84,13 +84,21 @@ def roofline_entry(name, ms, d, B, nnz_t, traffic):
     return e
 
 
+ONTOLOGY, DTYPE = "gobp", "f32"          # set from the command line (--ontology, --dtype)
+
+
 def build_model(device):
-    from onto_vae_amd.synthetic import StubOntobj, synthetic_masks
+    from onto_vae_amd.synthetic import StubOntobj, synthetic_masks, FULLGO_SYN_COUNTS, FULLGO_SYN_SEED
     from onto_vae_amd.vae_model import OntoVAE
-    masks = synthetic_masks()                                    # GOBP-syn, seed 20250117
-    onto = StubOntobj(masks, data={"d": np.zeros((2, masks[-1].shape[0]))}, description="GOBP-syn")
+    if ONTOLOGY == "fullgo":                                     # Full-GO-syn: T = 4500, K = 14
+        masks = synthetic_masks(FULLGO_SYN_COUNTS, 20000, FULLGO_SYN_SEED)
+    else:
+        masks = synthetic_masks()                                # GOBP-syn, seed 20250117
+    onto = StubOntobj(masks, data={"d": np.zeros((2, masks[-1].shape[0]))}, description=ONTOLOGY + "-syn")
     torch.manual_seed(0)
     model = OntoVAE(onto, "d", neuronnum=3, drop=0.0, z_drop=0.0)   # timing model: dropout off
+    if DTYPE == "bf16":
+        model.set_precision("bf16")                              # configs[4]: bf16 MFMA for x W0^T and dW0, the rest fp32
     return model, masks
 
 
@@ -206,6 +214,22 @@ def infer_bench(a, model, dev, world, rank, steps=None, warmup=None):
         "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                      "frac": t_mfma / sec, "traffic": None, "kernel": "whole step (encoder GEMM dominates)",
                      "algorithmic_flops": flops}}
+
+
+def host_infer_bench(model, dev, N=32768):
+    """get_pathway_activities as a user calls it: the dataset is a float64 numpy array in HOST memory (what Ontobj.data
+    holds, onto_vae/ontobj.py:495) and the result a numpy array; OntoVAE._pass_data pipelines conversion to float32 into
+    pinned memory, the copy up, the kernels and the copy down.  PCIe-inclusive: never the headline `value`."""
+    e = model._engine
+    X = synth_X(N, e.plan.G, dev, seed=4321).cpu().double().numpy()
+    model._pass_data(X[:4096], 'act')                     # warm-up (streams, pinned buffers of the allocator)
+    t0 = time.perf_counter()
+    act = model._pass_data(X, 'act')
+    dt = time.perf_counter() - t0
+    assert act.shape == (N, e.plan.T) and np.isfinite(act[:16]).all()
+    return {"metric": "inference samples/sec from a host-resident float64 dataset (PCIe-inclusive)", "value": N / dt, "unit": "samples/s",
+            "rows": N, "seconds": dt, "batch": int(model.inference_batch),
+            "host_to_device_GBps": N * e.plan.G * 4 / dt / 1e9}
 
 
 def screen_bench(a, model, dev, world, rank, steps=None, warmup=None):
@@ -364,10 +388,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="train mode, one GPU: skip the inference / screen / global-batch legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-phase times to stderr")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: BASELINE.json configs[4], the two large dense products on bf16 MFMA (fp32 accumulation, fp32 weights)")
+    ap.add_argument("--ontology", choices=["gobp", "fullgo"], default="gobp", help="fullgo: the deeper Full-GO-syn of configs[4]")
     ap.add_argument("--mode", choices=["train", "infer", "screen"], default="train",
                     help="infer: BASELINE.json configs[3], get_pathway_activities-equivalent (ontovae_pass_data, 'act' output) over "
                          "the HBM-resident rows in batches of --batch (default 16384 there); a step is one batch")
     a = ap.parse_args()
+    global ONTOLOGY, DTYPE
+    ONTOLOGY, DTYPE = a.ontology, a.dtype
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -411,6 +440,10 @@ def main():
     if workload is None:
         workload = ("BASELINE.json configs[1]: GOBP-syn OntoVAE (G=20000, T=3000, K=12, nu=3, L=360) "
                     "fp32 train step, batch 128 per GPU, lr 1e-4, kl_coeff 1e-4, dropout off")
+    if a.dtype == "bf16" or a.ontology == "fullgo":
+        workload = (f"BASELINE.json configs[4]: {'Full-GO-syn (T=4500, K=14, L=600)' if a.ontology == 'fullgo' else 'GOBP-syn'} OntoVAE, "
+                    f"{'bf16 MFMA variant (x W0^T and dW0 on bf16 inputs, fp32 accumulation, fp32 master weights and AdamW)' if a.dtype == 'bf16' else 'fp32'}"
+                    f", global batch {B * world} = {world} x {B} rows")
     Bg = B * world
     nnz_t = int(e.plan.rowptr[d.C])
 
@@ -454,7 +487,7 @@ def main():
                       (40.0 * P_real + 4.0 * d.G * B) / (PEAK_HBM_GBS * 1e9))
         out = {"metric": "train samples/sec (GO-BP OntoVAE fwd+bwd+step)", "value": value, "unit": "samples/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": workload, "batch_per_gpu": B, "global_batch": Bg, "dataset_rows": max(a.rows, Bg),
                           "parallelism": f"dp{world}" if world > 1 else "single"},
                "roofline": roof, "step_roofline_frac": t_bound / (dt / a.steps),
@@ -463,12 +496,13 @@ def main():
                "final_loss": final_loss}
         if single_same is not None:
             out["single_gpu_same_global_batch"] = single_same
-        if world == 1 and not a.no_extras and B == 128 and a.global_batch is None:
+        if world == 1 and not a.no_extras and B == 128 and a.global_batch is None and a.dtype == "f32" and a.ontology == "gobp":
             # the other headline workloads, measured after the timed region so that the driver's run covers them too
             xa = argparse.Namespace(**vars(a))
             xa.batch, xa.rows = None, 65536
             inf = infer_bench(xa, model, dev, 1, 0, steps=20, warmup=3)
             out["inference"] = {k: inf[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline")}
+            out["inference_from_host"] = host_infer_bench(model, dev)
             scr = screen_bench(xa, model, dev, 1, 0, steps=100, warmup=10)
             out["screen"] = {k: scr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline")}
             m2, _ = build_model(dev)

@@ -180,18 +180,29 @@ typedef struct ontovae_ctx {
     uint32_t flags;            /* ONTOVAE_FLAG_*: force the general-purpose kernel variants (tests) */
     ontovae_sell_t sell_fwd;   /* n_slices == 0: not provided, the per-level kernels run instead */
     ontovae_sell_t sell_bwd;
+    /* operand copies of the bf16-MFMA variant (ONTOVAE_FLAG_BF16_GEMM): ontovae_bf16_workspace_bytes(dims, max_batch) bytes of
+     * device memory, 256-B aligned; NULL / 0 otherwise */
+    void* bf16_ws;
+    int64_t bf16_ws_bytes;
 } ontovae_ctx_t;
 
 #define ONTOVAE_FLAG_LEVEL_LAUNCHES 1u  /* one launch per decoder level instead of the LDS-fused chain */
 #define ONTOVAE_FLAG_ROW_GENE_LAYER 2u  /* row-per-wave gene layer instead of the LDS-tiled one */
 #define ONTOVAE_FLAG_WIDE_GENE_TILES 8u /* gene layer: waves that span 64-256 batch columns instead of XCD-pinned 32-column blocks */
 /* Any other bit is refused with ONTOVAE_EINVAL (measurement switches exist only in -DOV_MEASUREMENT_SWITCHES builds). */
+/* BASELINE.json configs[4], "bf16 MFMA variant": the two large dense products of a pass -- x W0^T (onto_vae/modules.py:46) and its
+ * weight gradient dW0 = dh x -- take their inputs rounded to bf16 and accumulate in fp32 on v_mfma_f32_32x32x16_bf16; weights,
+ * optimizer state and every other operation stay fp32.  Stated tolerance against the fp32 reference path (tests): loss 2e-2
+ * relative per step, pathway activities cosine >= 0.999 per sample.  Needs ctx->bf16_ws, ctx->Gr (dW0 is staged there) and
+ * G % 8 == 0.  The gathered-dh data-parallel form (ontovae_dw0_global) stays fp32. */
+#define ONTOVAE_FLAG_BF16_GEMM     32u
 #define ONTOVAE_FLAG_NO_RIDERS     16u  /* weight gradient of the gene rows as its own launch instead of inside the backward chain's */
 #define ONTOVAE_FLAG_SIDE_STREAM    4u  /* run the decoder weight gradient and dWh on a library-owned second stream, forked from
                                            and joined into the caller's stream with events (off by default: on this pool the event
                                            hand-offs cost about what the overlap gains) */
 
 int64_t ontovae_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch);
+int64_t ontovae_bf16_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch);
 
 /* AdamW hyper-parameters of one step, pre-folded on the host in double like torch does
  * (torch.optim.AdamW defaults at onto_vae/vae_model.py:251). */

@@ -7,6 +7,7 @@
 #include "ontovae_internal.h"
 #include "ontovae_device.h"
 #include "ontovae_gemm.h"
+#include "ontovae_bf16.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -24,7 +25,7 @@
 
 #define OV_LAUNCH_CHECK() OV_HIP_CHECK(hipGetLastError())
 
-#define OV_KNOWN_FLAGS (ONTOVAE_FLAG_LEVEL_LAUNCHES | ONTOVAE_FLAG_ROW_GENE_LAYER | ONTOVAE_FLAG_SIDE_STREAM | ONTOVAE_FLAG_WIDE_GENE_TILES | ONTOVAE_FLAG_NO_RIDERS)
+#define OV_KNOWN_FLAGS (ONTOVAE_FLAG_LEVEL_LAUNCHES | ONTOVAE_FLAG_ROW_GENE_LAYER | ONTOVAE_FLAG_SIDE_STREAM | ONTOVAE_FLAG_WIDE_GENE_TILES | ONTOVAE_FLAG_NO_RIDERS | ONTOVAE_FLAG_BF16_GEMM)
 
 // batch columns per wave pass (64 lanes x VEC) and the padded row length, a multiple of it
 // -------------------------------------------------------------------------------------------------
@@ -175,6 +176,31 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs
 extern "C" int64_t ontovae_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch) {
     if (!dims || max_batch < 1) return -1;
     return ov_carve(*dims, max_batch, nullptr, nullptr);
+}
+
+// Operand copies of the bf16-MFMA variant (ONTOVAE_FLAG_BF16_GEMM): xb [max_batch, G], xT [G, ldb(max_batch)], wb [L, G],
+// dhb [L, ldb(max_batch)], 16-bit elements, 256-B aligned pieces of ctx->bf16_ws
+struct OvBfWs { uint16_t *xb, *xT, *wb, *dhb; };
+static int64_t ov_bf16_carve(const ontovae_dims_t& d, int max_batch, void* base, OvBfWs* w) {
+    const int64_t ldb = ov_ldb(max_batch);
+    int64_t off = 0;
+    auto take = [&](int64_t n) {
+        uint16_t* p = base ? reinterpret_cast<uint16_t*>(base) + off : nullptr;
+        off += (n + 127) / 128 * 128;
+        return p;
+    };
+    OvBfWs r;
+    r.xb = take((int64_t)max_batch * d.G);
+    r.xT = take((int64_t)d.G * ldb);
+    r.wb = take((int64_t)d.L * d.G);
+    r.dhb = take((int64_t)d.L * ldb);
+    if (w) *w = r;
+    return off * (int64_t)sizeof(uint16_t);
+}
+
+extern "C" int64_t ontovae_bf16_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch) {
+    if (!dims || max_batch < 1) return -1;
+    return ov_bf16_carve(*dims, max_batch, nullptr, nullptr);
 }
 
 // =================================================================================================
@@ -1959,6 +1985,14 @@ static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
                           (long long)ov_carve(d, c->max_batch, nullptr, nullptr));
         return ONTOVAE_EINVAL;
     }
+    if (c->flags & ONTOVAE_FLAG_BF16_GEMM) {
+        if (d.G % 8) { ontovae_set_error("ctx: the bf16 variant needs a gene count that is a multiple of 8 (G = %d)", d.G); return ONTOVAE_EINVAL; }
+        if (!c->bf16_ws || (reinterpret_cast<uintptr_t>(c->bf16_ws) & 255) || c->bf16_ws_bytes < ov_bf16_carve(d, c->max_batch, nullptr, nullptr)) {
+            ontovae_set_error("ctx: ONTOVAE_FLAG_BF16_GEMM needs bf16_ws of %lld bytes, 256-B aligned (ontovae_bf16_workspace_bytes)",
+                              (long long)ov_bf16_carve(d, c->max_batch, nullptr, nullptr));
+            return ONTOVAE_EINVAL;
+        }
+    }
 #ifndef OV_MEASUREMENT_SWITCHES
     if (c->flags & ~(uint32_t)OV_KNOWN_FLAGS) {
         ontovae_set_error("ctx: unknown flag bits 0x%x (known: 0x%x)", c->flags & ~(uint32_t)OV_KNOWN_FLAGS, (unsigned)OV_KNOWN_FLAGS);
@@ -2067,6 +2101,7 @@ struct OvStep {
     struct OvSide* side;     // internal second stream of this device, or NULL (ONTOVAE_FLAG_SINGLE_STREAM / creation failed)
     float* fm_out;           // screen passes: feature-major activity matrix the term levels write their nu-means to, or NULL
     int64_t fm_ld;
+    bool want_xT;            // bf16 variant: the encoder's conversion pass also writes the transposed copy of x (training steps)
 };
 
 // Independent branches of a step run on a library-owned second stream, forked from and joined back into
@@ -2121,8 +2156,45 @@ static int ov_side_join(OvStep& s) {
 }
 static inline hipStream_t ov_side_stream(const OvStep& s) { return s.side ? s.side->st : s.st; }
 
+static int ov_bf16_gemm(const OvBfGemm& g, int S, hipStream_t st) {
+    if (g.M < 1 || g.N < 1 || g.K < 1) return ONTOVAE_OK;
+    if ((g.K % 8) || (g.lda % 8) || (g.ldb % 8) || (g.kchunk % OV_BF_BK) || !ov_al16(g.A) || !ov_al16(g.B)) {
+        ontovae_set_error("bf16 gemm: K = %d, lda = %lld, ldb = %lld, kchunk = %d or operand alignment not supported", g.K, (long long)g.lda,
+                          (long long)g.ldb, g.kchunk);
+        return ONTOVAE_EINVAL;
+    }
+    hipLaunchKernelGGL(ov_bf16_gemm_tn_kernel, dim3((g.N + OV_BF_BN - 1) / OV_BF_BN, (g.M + OV_BF_BM - 1) / OV_BF_BM, S), dim3(256), 0, st, g);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
+// bf16 variant of ov_enc_gemm: W0 -> wb, batch rows of x -> xb (+ xT for the dW0 product of a training step), then the product
+static int ov_enc_gemm_bf16(OvStep& s, int* S_out) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_dims_t& d = c->dims;
+    OvBfWs bw;
+    ov_bf16_carve(d, c->max_batch, c->bf16_ws, &bw);
+    OvProfScope prof(ONTOVAE_PHASE_ENC_GEMM, s.st);
+    const int64_t nw = (int64_t)d.L * d.G;
+    hipLaunchKernelGGL(ov_bf16_convert_kernel, dim3((unsigned)std::min<int64_t>((nw / 8 + 255) / 256, 4096)), dim3(256), 0, s.st,
+                       c->P + c->lay.W0, bw.wb, nw);
+    OV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ov_bf16_x_kernel, dim3((d.G + 63) / 64, s.ldb / 64), dim3(256), 0, s.st, s.x, s.xidx, s.xld, s.B, d.G, bw.xb,
+                       s.want_xT ? bw.xT : (uint16_t*)nullptr, (int64_t)s.ldb);
+    OV_LAUNCH_CHECK();
+    const int tiles = ((d.L + OV_BF_BM - 1) / OV_BF_BM) * ((s.B + OV_BF_BN - 1) / OV_BF_BN);
+    int S = std::max(1, std::min(std::min((512 + tiles - 1) / tiles, 64), std::max(1, d.G / 512)));
+    S = (int)std::min<int64_t>(S, std::max<int64_t>(1, s.ws.slab_floats / ((int64_t)d.L * s.ldb)));
+    const int kchunk = ((d.G + S - 1) / S + OV_BF_BK - 1) / OV_BF_BK * OV_BF_BK;
+    const int Seff = (d.G + kchunk - 1) / kchunk;
+    *S_out = Seff;
+    const OvBfGemm g{bw.wb, d.G, bw.xb, d.G, s.ws.slab, s.ldb, (int64_t)d.L * s.ldb, d.L, s.B, d.G, kchunk};
+    return ov_bf16_gemm(g, Seff, s.st);
+}
+
 // x W0^T -> split-K slabs  (modules.py:46)
 static int ov_enc_gemm(OvStep& s, int* S_out) {
+    if (s.c->flags & ONTOVAE_FLAG_BF16_GEMM) return ov_enc_gemm_bf16(s, S_out);
     const ontovae_dims_t& d = s.c->dims;
     const int S = ov_enc_splitk(d.L, s.B, d.G);
     int kchunk = (d.G + S - 1) / S;
@@ -2455,6 +2527,7 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->side = nullptr;
     s->fm_out = nullptr;
     s->fm_ld = 0;
+    s->want_xT = false;
     return ONTOVAE_OK;
 }
 
@@ -2867,6 +2940,26 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply, int l0 = 0, 
     const ontovae_dims_t& d = c->dims;
     if (l1 < 0) l1 = d.L;
     const int64_t roff = (int64_t)l0 * d.G;
+    if (c->flags & ONTOVAE_FLAG_BF16_GEMM) {
+        // bf16 variant: dh rows -> dhb, dW0 rows = dhb . xT^T into the gradient buffer, then (fused-update callers) the flat AdamW
+        if (!c->Gr) { ontovae_set_error("dW0 (bf16 variant): the gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+        OvBfWs bw;
+        ov_bf16_carve(d, c->max_batch, c->bf16_ws, &bw);
+        OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
+        hipLaunchKernelGGL(ov_bf16_convert_rows_kernel, dim3((s.ldb + 1023) / 1024, l1 - l0), dim3(256), 0, s.st,
+                           s.ws.dh + (int64_t)l0 * s.ldb, (int64_t)s.ldb, s.B, bw.dhb + (int64_t)l0 * s.ldb, (int64_t)s.ldb);
+        OV_LAUNCH_CHECK();
+        const OvBfGemm bg{bw.dhb + (int64_t)l0 * s.ldb, s.ldb, bw.xT, s.ldb, c->Gr + c->lay.W0 + roff, d.G, 0, l1 - l0, d.G, s.ldb,
+                          (s.ldb + OV_BF_BK - 1) / OV_BF_BK * OV_BF_BK};
+        int rcb = ov_bf16_gemm(bg, 1, s.st);
+        if (rcb || !apply) return rcb;
+        const int64_t n = (int64_t)(l1 - l0) * d.G;
+        hipLaunchKernelGGL(ov_adamw_flat_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s.st,
+                           c->P + c->lay.W0 + roff, c->M + c->lay.W0 + roff, c->V + c->lay.W0 + roff, c->Gr + c->lay.W0 + roff, n,
+                           (int64_t)-1, (int64_t)-1, ov_adam_from(opt));
+        OV_LAUNCH_CHECK();
+        return ONTOVAE_OK;
+    }
     OvGemm g{};
     g.M = l1 - l0; g.N = d.G; g.K = s.B;
     g.A = s.ws.dh + (int64_t)l0 * s.ldb; g.lda = s.ldb;
@@ -2903,9 +2996,11 @@ extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, cons
     if (!x || !loss_out) { ontovae_set_error("train_step: x or loss_out is NULL"); return ONTOVAE_EINVAL; }
     if (apply_update && !opt) { ontovae_set_error("train_step: opt is NULL"); return ONTOVAE_EINVAL; }
     if (!apply_update && !ctx->Gr) { ontovae_set_error("train_step: gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+    if ((ctx->flags & ONTOVAE_FLAG_BF16_GEMM) && !ctx->Gr) { ontovae_set_error("train_step: the bf16 variant stages dW0 in the gradient buffer, Gr is NULL"); return ONTOVAE_EINVAL; }
     if (B < 2) { ontovae_set_error("train_step: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
     OvStep s;
     ov_make_step(ctx, x, xidx, B, stream, &s);
+    s.want_xT = true;
     s.side = ov_side_get(ctx);
     bool refreshed = false;
     if (s.side && ov_fused_bt(ctx) != 0 && OV_DBG((ctx->flags & 32u) != 0)) {      // packed decoder weight copies || encoder (measurement only)
@@ -2930,6 +3025,7 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
     if (B_global < 2 || B_global < B) { ontovae_set_error("train_step_dp: bad global batch %d (local %d)", B_global, B); return ONTOVAE_EINVAL; }
     OvStep s;
     ov_make_step(ctx, x, xidx, B, stream, &s);
+    s.want_xT = true;
     if (phase == 0) {
         int S = 1;
         if ((rc = ov_enc_gemm(s, &S))) return rc;

@@ -61,7 +61,8 @@ class Engine:
         self._idx = None
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self.rng_offset = 0
-        self.flags = 0          # _lib FLAG_* bits: force the general-purpose kernel variants (tests)
+        self.flags = 0          # _lib FLAG_* bits: force the general-purpose kernel variants (tests), bf16 variant
+        self._bf16_ws = None
         self._upload_plan()
 
     # ------------------------------------------------------------------ views of the flat buffer
@@ -204,6 +205,12 @@ class Engine:
             self._ws = None
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
             self.max_batch = mb
+            self._bf16_ws = None
+            self._ctx = None
+        if (self.flags & _lib.FLAG_BF16_GEMM) and getattr(self, "_bf16_ws", None) is None:
+            nb16 = L.ontovae_bf16_workspace_bytes(C.byref(self.plan.dims), self.max_batch)
+            self._bf16_ws = torch.zeros(nb16 + 256, dtype=torch.uint8, device=self.device)
+            self.ensure_grad_buffer()          # the bf16 dW0 product is staged in the gradient buffer
             self._ctx = None
         if self._ctx is None:
             c = _lib.Ctx()
@@ -232,10 +239,28 @@ class Engine:
             c.max_batch = self.max_batch
             c.drop, c.z_drop, c.seed = self.drop, self.z_drop, self.seed
             c.flags = self.flags
+            if self.flags & _lib.FLAG_BF16_GEMM:
+                b16 = self._bf16_ws.data_ptr()
+                a16 = (b16 + 255) // 256 * 256
+                c.bf16_ws = C.c_void_p(a16)
+                c.bf16_ws_bytes = self._bf16_ws.numel() - (a16 - b16)
             self._ctx = c
         return self._ctx
 
     def invalidate(self):
+        self._ctx = None
+
+    def set_precision(self, mfma_dtype):
+        """'f32' (default: everything in float32, the reference's precision) or 'bf16' (BASELINE.json configs[4]: the two
+        large dense products x W0^T and dW0 = dh x on bf16 MFMA with fp32 accumulation; weights and AdamW stay fp32)."""
+        if mfma_dtype not in ("f32", "bf16"):
+            raise ValueError("mfma_dtype must be 'f32' or 'bf16'")
+        if mfma_dtype == "bf16":
+            if self.plan.G % 8:
+                raise ValueError(f"the bf16 variant needs a gene count that is a multiple of 8, got {self.plan.G}")
+            self.flags |= _lib.FLAG_BF16_GEMM
+        else:
+            self.flags &= ~_lib.FLAG_BF16_GEMM
         self._ctx = None
 
     def stream(self):

@@ -126,6 +126,13 @@ class OntoVAE(nn.Module):
         self.screen_rank1 = True
 
     # ------------------------------------------------------------------ plumbing
+    def set_precision(self, mfma_dtype):
+        """Not in the reference.  'f32' (default) or 'bf16': BASELINE.json configs[4], the two large dense products of a pass
+        (x W0^T and its weight gradient) on bf16 MFMA with fp32 accumulation; parameters, optimizer and everything else stay
+        float32.  Stated tolerance against the float32 path: loss 2e-2 relative per step, activities cosine >= 0.999."""
+        self._engine.set_precision(mfma_dtype)
+        return self
+
     @property
     def mask_list(self):
         """vae_model.py:51-52: the masks as float32 tensors (built on access, they are dense)."""
@@ -296,32 +303,82 @@ class OntoVAE(nn.Module):
 
     def _pass_data(self, data, output):
         """vae_model.py:276-327, streamed in batches: eval mode, two eps draws per sample, the
-        nu-mean and the [z | activities] concatenation done on the device."""
+        nu-mean and the [z | activities] concatenation done on the device.
+
+        The reference moves the whole dataset to the device in one tensor (vae_model.py:349).  Here a dataset that lives in
+        host memory goes through a three-stage pipeline: while the kernels of batch i run, batch i + 1 is converted to
+        float32 into pinned memory and copied up on a second stream, and the result of batch i - 1 is copied down on a
+        third one into the (pinned) result array.  A dataset that is already a device tensor is read in place."""
         self.eval()
         e = self._engine
-        data = torch.as_tensor(data, dtype=torch.float32)
-        N = data.shape[0]
+        e._require_gpu()
         T, G = e.plan.T, e.plan.G
-        out = torch.empty(N, T if output == 'act' else G, dtype=torch.float32, device=e.device)
-        step = int(self.inference_batch)
-        for i in range(0, N, step):
-            xb = data[i:i + step].to(e.device)
-            B = xb.shape[0]
-            eps1, eps2 = self._eps(B), self._eps(B)
-            if output == 'act':
-                e.pass_data(xb, None, eps1, eps2, act_out=out[i:i + B])
-            else:
-                e.pass_data(xb, None, eps1, eps2, rec_out=out[i:i + B])
-        return out.cpu().numpy()
+        W = T if output == 'act' else G
+        key = 'act_out' if output == 'act' else 'rec_out'
+        step = max(int(self.inference_batch), 1)
+        if isinstance(data, torch.Tensor) and data.device == e.device:
+            data = data.to(torch.float32)
+            N = data.shape[0]
+            out = torch.empty(N, W, dtype=torch.float32, device=e.device)
+            for i in range(0, N, step):
+                xb = data[i:i + step]
+                B = xb.shape[0]
+                e.pass_data(xb, None, self._eps(B), self._eps(B), **{key: out[i:i + B]})
+            return out.cpu().numpy()
+        src = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data))
+        if src.dim() != 2 or src.shape[1] != G:
+            raise ValueError(f"expected data of shape [N, {G}], got {tuple(src.shape)}")
+        N = src.shape[0]
+        result = torch.empty(N, W, dtype=torch.float32, pin_memory=True)
+        if N == 0:
+            return result.numpy()
+        nbuf = 2
+        rows = min(step, N)
+        with torch.cuda.device(e.device):
+            main = torch.cuda.current_stream(e.device)
+            s_in, s_out = torch.cuda.Stream(e.device), torch.cuda.Stream(e.device)
+            hin = [torch.empty(rows, G, dtype=torch.float32, pin_memory=True) for _ in range(nbuf)]
+            din = [torch.empty(rows, G, dtype=torch.float32, device=e.device) for _ in range(nbuf)]
+            dout = [torch.empty(rows, W, dtype=torch.float32, device=e.device) for _ in range(nbuf)]
+            up = [torch.cuda.Event() for _ in range(nbuf)]        # batch is in din[k]
+            done = [torch.cuda.Event() for _ in range(nbuf)]      # kernels of the batch in slot k finished (din[k] free, dout[k] full)
+            down = [torch.cuda.Event() for _ in range(nbuf)]      # dout[k] copied to the host (dout[k] free)
+            used = [False] * nbuf
+            for n, i in enumerate(range(0, N, step)):
+                k = n % nbuf
+                B = min(step, N - i)
+                if used[k]:
+                    up[k].synchronize()                           # hin[k] may be overwritten only after its copy went up
+                hin[k][:B].copy_(src[i:i + B])                    # float64 -> float32 on the host cores, into pinned memory
+                with torch.cuda.stream(s_in):
+                    if used[k]:
+                        s_in.wait_event(done[k])                  # the kernels that read din[k] two batches ago
+                    din[k][:B].copy_(hin[k][:B], non_blocking=True)
+                    up[k].record(s_in)
+                main.wait_event(up[k])
+                if used[k]:
+                    main.wait_event(down[k])
+                e.pass_data(din[k][:B], None, self._eps(B), self._eps(B), **{key: dout[k][:B]})
+                done[k].record(main)
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(done[k])
+                    result[i:i + B].copy_(dout[k][:B], non_blocking=True)
+                    down[k].record(s_out)
+                used[k] = True
+            s_out.synchronize()
+        return result.numpy()
 
     # ---- shared pieces of the three retrieval methods --------------------------------------
     def _key(self):
         return str(self.top) + '_' + str(self.bottom)
 
-    def _dataset_copy(self, ontobj, dataset):
+    def _dataset_copy(self, ontobj, dataset, copy=True):
+        """vae_model.py:343-346.  copy=False for the callers that only read the data (the reference copies there too, which
+        nothing can observe: the pass never writes to it)."""
         if self.ontology != ontobj.description:
             raise ValueError('Wrong ontology provided, should be ' + self.ontology)
-        return ontobj.data[self._key()][dataset].copy()
+        data = ontobj.data[self._key()][dataset]
+        return data.copy() if copy else data
 
     def _subset_terms(self, ontobj, res, terms):
         if terms is None:
@@ -337,12 +394,12 @@ class OntoVAE(nn.Module):
 
     def get_pathway_activities(self, ontobj, dataset, terms=None):
         """vae_model.py:330-361: [N, T] float32 activities, columns ordered by depth."""
-        data = self._dataset_copy(ontobj, dataset)
+        data = self._dataset_copy(ontobj, dataset, copy=False)
         return self._subset_terms(ontobj, self._pass_data(data, 'act'), terms)
 
     def get_reconstructed_values(self, ontobj, dataset, rec_genes=None):
         """vae_model.py:364-395: [N, G] float32 reconstruction."""
-        data = self._dataset_copy(ontobj, dataset)
+        data = self._dataset_copy(ontobj, dataset, copy=False)
         return self._subset_genes(ontobj, self._pass_data(data, 'rec'), rec_genes)
 
     def perturbation(self, ontobj, dataset, genes, values, output='terms', terms=None, rec_genes=None):

@@ -374,3 +374,78 @@ def test_dp_two_processes_gobp_syn_heuristic_forms(tmp_path, B, form):
     mask[int(lay.b0):int(lay.b0) + Lw] = False
     diff = np.abs(got[0]["P"] - want)[mask]
     assert (diff > 1e-6 + 1e-4 * np.abs(want[mask])).mean() <= 0.01 and diff.max() <= 2 * 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- configs[4], bf16 variant
+BF16_LOSS_REL = 2e-2        # stated tolerance of the bf16-MFMA variant against the float32 oracle: loss per step
+BF16_ACT_COS = 0.999        # pathway activities / reconstructions: cosine per sample
+
+
+def _cos_rows(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1) + 1e-300)
+
+
+@pytest.mark.parametrize("which", ["medium", "fullgo"])
+def test_bf16_variant_vs_oracle(which):
+    """BASELINE.json configs[4]: the bf16-MFMA variant (x W0^T and dW0 = dh x with bf16 inputs, fp32 accumulation, fp32 master
+    weights and AdamW) against the float32 oracle, at the tolerance the variant states: loss 2e-2 relative, activities cosine
+    >= 0.999; plus the gradient it changes (dW0: cosine and relative L2 error) and three AdamW steps.  'fullgo' is the deeper
+    Full-GO-syn ontology of SURVEY.md 8(d) config 5 (T = 4500, K = 14, L = 600: the panel takes 2 columns per workgroup)."""
+    from ontovae_oracle import OracleOntoVAE
+    from onto_vae_amd.synthetic import synthetic_masks, random_state_dict, FULLGO_SYN_COUNTS, FULLGO_SYN_SEED
+    from onto_vae_amd.vae_model import FusedAdamW
+    if which == "medium":
+        masks, sd = medium()
+        G, nu, B, lr = 1000, 3, 512, 1e-3
+    else:
+        masks = synthetic_masks(FULLGO_SYN_COUNTS, 20000, FULLGO_SYN_SEED)
+        sd = random_state_dict(masks, 3, 78, dense=False)
+        G, nu, B, lr = 20000, 3, 1024, 1e-4
+    L = masks[0].shape[1] * nu
+    rng = np.random.RandomState(31)
+    x = np.log1p(rng.poisson(0.3, size=(B, G))).astype(np.float32)
+    eps = rng.standard_normal((B, L)).astype(np.float32)
+    o = OracleOntoVAE(masks, nu)
+    o.load_state_dict(sd)
+    rec, kl, loss, g = o.gradients(x, eps, 1e-4)
+    model, onto = make_model(masks, nu, sd, X=x)
+    model.set_precision("bf16")
+    e = model._engine
+    out = torch.zeros(3, device="cuda")
+    e.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), 1e-4, None, out, apply_update=False)
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got, [rec, kl, loss], rtol=BF16_LOSS_REL)
+    assert abs(got[2] - loss) > 1e-7 * abs(loss)                 # it IS another arithmetic (the flag is not ignored)
+    gw, ww = e.view("W0", e.Gr).cpu().numpy().ravel(), g["encoder.encoder.0.0.weight"].ravel()
+    cos = float(gw @ ww / (np.linalg.norm(gw) * np.linalg.norm(ww)))
+    # dh is a cancelling quantity (every row sums to zero after the BatchNorm backward): bf16 rounding of dh and x leaves 3-5 % of
+    # relative L2 error in dW0
+    assert cos >= 0.995 and np.linalg.norm(gw - ww) <= 0.1 * np.linalg.norm(ww), (cos, np.linalg.norm(gw - ww) / np.linalg.norm(ww))
+    # inference in the variant: activities and reconstruction per sample
+    e1, e2 = rng.standard_normal((B, L)).astype(np.float32), rng.standard_normal((B, L)).astype(np.float32)
+    o2 = OracleOntoVAE(masks, nu)
+    o2.load_state_dict(sd)
+    imodel, ionto = make_model(masks, nu, sd, X=x)
+    imodel.set_precision("bf16")
+    feed(imodel, [e1, e2])
+    act = imodel.get_pathway_activities(ionto, "d")
+    assert _cos_rows(act, o2.pass_data(x, e1, e2, "act_only")).min() >= BF16_ACT_COS
+    # three fused steps: losses inside the stated tolerance, weights move the way the oracle's do
+    opt = FusedAdamW(model, lr=lr)
+    o3 = OracleOntoVAE(masks, nu)
+    o3.load_state_dict(sd)
+    m3, _ = make_model(masks, nu, sd)
+    m3.set_precision("bf16")
+    opt3 = FusedAdamW(m3, lr=lr)
+    outs = torch.zeros(3, 3, device="cuda")
+    want = []
+    for s_ in range(3):
+        xs = np.log1p(rng.poisson(0.3, size=(B, G))).astype(np.float32)
+        es = rng.standard_normal((B, L)).astype(np.float32)
+        want.append(o3.train_step(xs, es, lr, 1e-4))
+        m3._engine.train_step(torch.as_tensor(xs), None, torch.as_tensor(es), 1e-4, opt3.next_hyper(), outs[s_])
+    np.testing.assert_allclose(outs.cpu().numpy(), np.array(want), rtol=BF16_LOSS_REL)
+    w_hip, w_ref, w0 = m3._engine.view("W0").cpu().numpy(), o3.p["encoder.encoder.0.0.weight"], np.asarray(sd["encoder.encoder.0.0.weight"])
+    du_h, du_r = (w_hip - w0).ravel(), (w_ref - w0).ravel()
+    assert float(du_h @ du_r / (np.linalg.norm(du_h) * np.linalg.norm(du_r))) >= 0.9      # Adam's sign-like steps agree on most weights
