@@ -67,6 +67,7 @@ typedef struct ontovae_dims {
     int32_t C;        /* panel width  = nu * T                                         */
     int64_t nnz;      /* structurally non-zero decoder weights (expanded)              */
     int64_t nnz_links;/* ones in the input masks                                       */
+    int64_t nnz_term; /* of nnz, the entries of the K-1 term layers (rows [0, C) of the CSR)  */
 } ontovae_dims_t;
 
 /* masks[i]: row-major uint8 [rows[i], cols[i]], values 0/1.  Shapes are validated against the

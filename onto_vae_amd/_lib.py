@@ -23,7 +23,7 @@ c_u8p = C.POINTER(C.c_uint8)
 
 class Dims(C.Structure):
     _fields_ = [("G", C.c_int32), ("T", C.c_int32), ("K", C.c_int32), ("nu", C.c_int32), ("L", C.c_int32),
-                ("C", C.c_int32), ("nnz", C.c_int64), ("nnz_links", C.c_int64)]
+                ("C", C.c_int32), ("nnz", C.c_int64), ("nnz_links", C.c_int64), ("nnz_term", C.c_int64)]
 
 
 class Layout(C.Structure):

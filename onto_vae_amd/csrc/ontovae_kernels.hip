@@ -116,7 +116,7 @@ struct OvWs {
     float *slab, *xhat, *a, *mulv, *epsw, *act, *d, *dblk, *dmulv, *da, *dh;
     float *bn_mean, *bn_invstd, *bn_bwd_local;
     float *rec_part, *kl_part;
-    float *wpart;              // [ldb / 32][nnz + C + G] weight-gradient partials of the 32-column blocks
+    float *wpart;              // [ldb / 32][nnz + C + G + nnz_term] weight-gradient partials of the 32-column blocks
     int64_t slab_floats;
     int npart_max;
 };
@@ -166,7 +166,7 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs
     w.bn_bwd_local = take(2 * L);
     w.rec_part = take(npart);
     w.kl_part = take(npart);
-    w.wpart = take((ldb / 32) * ((int64_t)d.nnz + C + G));
+    w.wpart = take((ldb / 32) * ((int64_t)d.nnz + C + G + d.nnz_term));
     w.slab_floats = slab;
     w.npart_max = (int)npart;
     if (ws) *ws = w;
@@ -1338,6 +1338,67 @@ __device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const
     }
 }
 
+// ov_gather_grp<true, 1> for the gene part of the backward, with the weight gradient of the same links in the same pass.
+// The group works on panel node p; its list names the genes g below p (rowidx = node of g, kidx = position k of the
+// link in the packed weights).  Each gathered row D[g, cols] is used twice while it is in registers:
+//   acc  += w[k] * D[g, cols]                          (data gradient of p, as before)
+//   part[k] = sum over the block's columns of ACT[p, cols] * D[g, cols]    (weight gradient partial of link k)
+// so the weight gradient of the gene layer needs no gathers of its own (it used to re-read one ACT row per link in the
+// launches of the backward chain and of the latent backward).  The dot is reduced over the group's 8 lanes with 3 DPP
+// adds; lane s keeps entry s of the batch of 8 and stores it at its link's CSC position: the group's 8 lanes write 32
+// contiguous bytes, a node's list one contiguous run (the finish pass walks the links in CSC order too).
+__device__ __forceinline__ void ov_gather_grp_wgrad(f32x4& acc, int k0, int len, const int32_t* __restrict__ rowidx,
+                                                    const int32_t* __restrict__ kidx, const float* __restrict__ vals,
+                                                    const float* __restrict__ srccol, int ldb, int lane, const f32x4 aseg,
+                                                    float* __restrict__ part, const bool by_q) {
+    const int s = lane & 7;
+    int maxlen = len;                    // wave maximum of len
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    auto fetch = [&](int e, int& r, float& w, int& k) {
+        const int ee = max(min(e, len - 1), 0);
+        r = len > 0 ? rowidx[k0 + ee] : 0;
+        w = 0.f;
+        k = -1;
+        if (e < len) {          // k: where the link's partial goes, its CSC position (by_q) or its packed position
+            const int kk = kidx[k0 + e];
+            w = vals[kk];
+            k = by_q ? k0 + e : kk;
+        }
+    };
+    int cur_r, nxt_r = 0, cur_k, nxt_k = -1;
+    float cur_w, nxt_w = 0.f;
+    fetch(s, cur_r, cur_w, cur_k);
+    for (int b0 = 0; b0 < maxlen; b0 += 8) {
+        if (b0 + 8 < maxlen) fetch(b0 + 8 + s, nxt_r, nxt_w, nxt_k);
+        f32x4 v[8];
+        float w[8];
+#define OV_GW_STEP(I)                                                                                     \
+        {                                                                                                 \
+            const int r = ov_grp_bcast<I>(cur_r);                                                         \
+            w[I] = ov_grp_bcast<I>(cur_w);                                                                \
+            v[I] = *reinterpret_cast<const f32x4*>(srccol + (int64_t)r * ldb);                            \
+        }
+        OV_GW_STEP(0) OV_GW_STEP(1) OV_GW_STEP(2) OV_GW_STEP(3) OV_GW_STEP(4) OV_GW_STEP(5) OV_GW_STEP(6) OV_GW_STEP(7)
+#undef OV_GW_STEP
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc.x += w[i] * v[i].x; acc.y += w[i] * v[i].y;
+            acc.z += w[i] * v[i].z; acc.w += w[i] * v[i].w;
+            float t = v[i].x * aseg.x;
+            t += v[i].y * aseg.y;
+            t += v[i].z * aseg.z;
+            t += v[i].w * aseg.w;
+            t = ov_group_sum<3>(t);
+            mine = s == i ? t : mine;
+        }
+        if (cur_k >= 0) part[cur_k] = mine;
+        cur_r = nxt_r; cur_w = nxt_w; cur_k = nxt_k;
+    }
+}
+
 // The 32 rows of a tile are dealt to the lane groups in order of decreasing list length (rank by counting in
 // LDS), so that the 8 groups of a wave walk lists of similar length.  Call with all threads of the workgroup (tid is
 // the thread's number inside its 256-thread tile team; every team has its own three arrays); returns the
@@ -1367,7 +1428,8 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
                                                         const float* __restrict__ act, int B, int ldb,
                                                         const float* __restrict__ x, const int32_t* __restrict__ xidx, int G,
                                                         float* __restrict__ d, float* __restrict__ rec_part,
-                                                        float* __restrict__ rec_out, int64_t rec_ld, int C, int ncb, int ntiles) {
+                                                        float* __restrict__ rec_out, int64_t rec_ld, int C, int ncb, int ntiles,
+                                                        float* __restrict__ bpart, int bp_rows, int bp_row0) {
     constexpr int TG = 32, LD = 33;
     __shared__ float xs[TG * LD];
     __shared__ float red[4];
@@ -1419,6 +1481,11 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
                 o[c] = 2.f * dv;
             }
             *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = o;
+            if (bpart) {          // gradient of the gene's bias: sum of D[g, :] over the block's columns (same order as ov_wgrad_cb_body)
+                float gb = (o.x + o.y) + (o.z + o.w);
+                gb = ov_group_sum<3>(gb);
+                if ((lane & 7) == 7) bpart[(int64_t)map.cb * bp_rows + bp_row0 + g] = gb;
+            }
         }
         sq = ov_wave_sum(sq);
         if (lane == 0) red[wave] = sq;
@@ -1442,10 +1509,13 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
 
 // Gene part of the backward on 32-column blocks: D[p, cols] = sum over the genes g of column p of W[g, p] * D[g, cols].
 // 4 waves, 32 panel nodes per workgroup, one node per lane group.
+// wpart != NULL: also the weight-gradient partials of the gene layer's links, part[cb][k] (ov_gather_grp_wgrad).
 __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_split,
                                                             const int32_t* __restrict__ csc_row, const int32_t* __restrict__ csc_k,
                                                             const float* __restrict__ vals, float* __restrict__ d,
-                                                            float* __restrict__ dblk, int C, int ldb, int ncb, int ntiles) {
+                                                            float* __restrict__ dblk, int C, int ldb, int ncb, int ntiles,
+                                                            const float* __restrict__ act, float* __restrict__ wpart, int64_t nnz,
+                                                            int wpart_by_q) {
     __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
     const OvCbMap map = ov_cb_map(blockIdx.x, ncb, ntiles);
     if (map.tile >= ntiles) return;
@@ -1459,7 +1529,12 @@ __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __re
     int k0, len;
     const int node = map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    ov_gather_grp<true, OV_GENE_BWD_U>(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane);
+    if (wpart) {
+        const f32x4 aseg = *reinterpret_cast<const f32x4*>(act + (int64_t)min(node, C - 1) * ldb + col0 + s4);
+        ov_gather_grp_wgrad(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz, wpart_by_q != 0);
+    } else {
+        ov_gather_grp<true, OV_GENE_BWD_U>(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane);
+    }
     if (node < C) {
         // dblk: column-group-major [ldb / 4][C][4], what a workgroup of the backward chain loads in one piece
         if (dblk) *reinterpret_cast<f32x4*>(dblk + ((int64_t)(map.cb * 8 + (lane & 7)) * C + node) * 4) = acc;
@@ -1606,18 +1681,40 @@ struct OvFinishArgs {
     float* vals; float* mvals; float* vvals; float* gvals;
     float* bias; float* mbias; float* vbias; float* gbias;
     int apply_update; OvAdam adam;
+    // gene layer's partials formed by the backward gene kernel: part is indexed by the link's CSC position q (one
+    // coalesced stream per column block), tpart [ncb][nnz_term] holds the term layers' partials by packed position k
+    const float* tpart; int64_t nnz_term; const int32_t* csc_row; const int32_t* csc_k;
 };
 // first / stride: this thread's number and the thread count of the finish part
 __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, const int64_t first, const int64_t stride) {
-    for (int64_t k = first; k < a.nnz; k += stride) {
-        float g = 0.f;
-        for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
+    auto update = [&](int64_t k, float g) {
         if (a.apply_update) {
             float w = a.vals[k], m = a.mvals[k], v = a.vvals[k];
             ov_adamw(w, m, v, g, a.adam, true);
             a.vals[k] = w; a.mvals[k] = m; a.vvals[k] = v;
         } else {
             a.gvals[k] = g;
+        }
+    };
+    if (a.tpart) {
+        for (int64_t k = first; k < a.nnz_term; k += stride) {
+            float g = 0.f;
+            for (int cb = 0; cb < a.ncb; ++cb) g += a.tpart[(int64_t)cb * a.nnz_term + k];
+            update(k, g);
+        }
+        // gene links in CSC order: the partial sums are read as contiguous streams whatever the number of column blocks;
+        // what is scattered is one read-modify-write of (w, m, v) per link
+        for (int64_t q = first; q < a.nnz; q += stride) {
+            if (a.csc_row[q] < a.C) continue;                 // a term-to-term link: done above
+            float g = 0.f;
+            for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + q];
+            update(a.csc_k[q], g);
+        }
+    } else {
+        for (int64_t k = first; k < a.nnz; k += stride) {
+            float g = 0.f;
+            for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
+            update(k, g);
         }
     }
     for (int64_t r = first; r < a.nrows; r += stride) {
@@ -2102,6 +2199,9 @@ struct OvStep {
     float* fm_out;           // screen passes: feature-major activity matrix the term levels write their nu-means to, or NULL
     int64_t fm_ld;
     bool want_xT;            // bf16 variant: the encoder's conversion pass also writes the transposed copy of x (training steps)
+    // training, column-block kernels: the gene layer's weight gradient is formed inside the gene-layer kernels themselves
+    // (bias partials in the forward kernel, link partials in the backward kernel); NULL = not wanted
+    float* gw_part; float* gw_bpart; int gw_rows, gw_row0; bool gw_by_q;
 };
 
 // Independent branches of a step run on a library-owned second stream, forked from and joined back into
@@ -2412,7 +2512,8 @@ static int ov_dec_gene(OvStep& s, float* rec_out, int64_t rec_ld) {
     if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
         const int ncb = s.ldb / 32, ntiles = (d.G + 31) / 32;
         hipLaunchKernelGGL((ov_gene_cb_kernel<MODE>), dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->rowptr, c->colidx, vals, bias,
-                           s.ws.act, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C, ncb, ntiles);
+                           s.ws.act, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C, ncb, ntiles,
+                           MODE == 1 ? s.gw_bpart : (float*)nullptr, s.gw_rows, s.gw_row0);
         OV_LAUNCH_CHECK();
         return ONTOVAE_OK;
     }
@@ -2424,6 +2525,12 @@ static int ov_dec_gene(OvStep& s, float* rec_out, int64_t rec_ld) {
 #undef OV_GT
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
+}
+
+// the training-mode gene layer goes through the column-block kernel (must match ov_dec_gene<1>)
+static bool ov_gene_cb_on(const OvStep& s) {
+    const ontovae_dims_t& d = s.c->dims;
+    return (d.G % 4 == 0) && !(s.c->flags & (ONTOVAE_FLAG_ROW_GENE_LAYER | ONTOVAE_FLAG_WIDE_GENE_TILES)) && ov_al16(s.x) && (s.xld % 4 == 0);
 }
 
 // number of sum-of-squares partials the gene layer wrote (must match ov_dec_gene<1>)
@@ -2468,7 +2575,7 @@ static int ov_dec_backward(OvStep& s, const OvWgradArgs* wg = nullptr, bool* wg_
         const int ncb = s.ldb / 32, ntiles = (d.C + 31) / 32;
         if (bt == 4) blk = s.ws.dblk;           // the chain's workgroups take 4 columns each: hand them contiguous pieces
         hipLaunchKernelGGL(ov_bwd_gene_cb_kernel, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row,
-                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles);
+                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles, s.ws.act, s.gw_part, (int64_t)d.nnz, s.gw_by_q ? 1 : 0);
         OV_LAUNCH_CHECK();
     } else {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
@@ -2528,6 +2635,7 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->fm_out = nullptr;
     s->fm_ld = 0;
     s->want_xT = false;
+    s->gw_part = nullptr; s->gw_bpart = nullptr; s->gw_rows = 0; s->gw_row0 = 0; s->gw_by_q = false;
     return ONTOVAE_OK;
 }
 
@@ -2802,25 +2910,29 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     if ((rc = ov_reparam(s, eps, 1, rng_off, OV_RNG_EPS, 1, &nkl, !refreshed))) return rc;
     if (refreshed && (rc = ov_side_join(s))) return rc;          // packed decoder weights ready
     if ((rc = ov_dec_forward_terms(s, true))) return rc;
-    if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
     // weight gradient of the decoder: rows = nodes [0, C - L) (term rows), then the genes; entries = packed range [0, nnz)
     const int n_term_rows = d.C - d.L;
     const int wrows = n_term_rows + d.G;
     const bool wcb = !(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES);
+    // The gene layer's own weight gradient is formed inside its two column-block kernels (bias partials in the forward one,
+    // link partials in the backward one, which has every D row it needs in registers anyway): no gathers of its own.
+    // ONTOVAE_FLAG_NO_RIDERS keeps the stand-alone weight-gradient kernels for all rows (tests compare the two).
+    const bool fused_gw = wcb && ov_gene_cb_on(s) && ov_fused_bt(c) != 0 && !s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS);
     OvWgradArgs wa{};
     int ride_rows = 0;
     if (wcb) {
         const int ncb = s.ldb / 32;
-        // a share of the gene rows, sized so that the riders finish about when the chain does (they run at half their
-        // usual occupancy there: one 1024-thread workgroup per CU next to the chain's LDS reservation)
-        ride_rows = std::min<int64_t>(d.G, ((int64_t)d.G * OV_RIDE_PCT / 100 + 31) / 32 * 32);
+        ride_rows = fused_gw ? d.G : 0;          // gene rows done elsewhere
         wa = OvWgradArgs{c->rowptr, c->colidx, s.ws.act, s.ws.d, s.ws.wpart, s.ws.wpart + (int64_t)ncb * d.nnz, (int64_t)d.nnz,
                          wrows - ride_rows, ride_rows, wrows, 0, n_term_rows, d.C, s.ldb, ncb, (ride_rows + 31) / 32};
+        // Where a link's partial is stored: at its packed position k (a scattered 4-B store per link and column block, a
+        // coalesced finish pass) or at its CSC position (contiguous stores, ONE scattered read-modify-write of (w, m, v) per
+        // link in the finish pass, ~22 us at GO-BP scale whatever the batch).  Measured cross-over: 16 column blocks.
+        if (fused_gw) { s.gw_part = wa.part; s.gw_bpart = wa.bpart; s.gw_rows = wrows; s.gw_row0 = n_term_rows; s.gw_by_q = ncb >= 16; }
     }
-    // the gene rows need only the gene layer's D rows: they ride in the backward chain's launch (on the CUs it leaves idle)
-    bool wgene_done = false;
-    const bool ride = wcb && !s.side && ride_rows > 0 && !(c->flags & ONTOVAE_FLAG_NO_RIDERS);
-    if ((rc = ov_dec_backward(s, ride ? &wa : nullptr, &wgene_done))) return rc;
+    if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
+    const bool wgene_done = fused_gw;
+    if ((rc = ov_dec_backward(s))) return rc;
     // fork: the decoder's weight gradients need nothing from the encoder backward, and vice versa
     if ((rc = ov_side_fork(s))) return rc;
     const hipStream_t sst = ov_side_stream(s);
@@ -2840,7 +2952,15 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         fa = OvFinishArgs{wa.part, wa.bpart, wa.ncb, (int64_t)d.nnz, wrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,
                           c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                           G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
-                          c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam};
+                          c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam,
+                          nullptr, 0, nullptr, nullptr};
+        if (fused_gw && s.gw_by_q) {
+            // term rows: partials by packed position in their own region; gene links: by CSC position in wa.part
+            float* tpart = s.ws.wpart + (int64_t)wa.ncb * ((int64_t)d.nnz + d.C + d.G);
+            wt.part = tpart;
+            wt.nnz = d.nnz_term;
+            fa.tpart = tpart; fa.nnz_term = d.nnz_term; fa.csc_row = c->csc_row; fa.csc_k = c->csc_k;
+        }
     }
     if (!riders2) {
         OvProfScope prof(ONTOVAE_PHASE_DEC_WGRAD, sst);

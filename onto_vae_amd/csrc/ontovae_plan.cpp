@@ -296,6 +296,7 @@ static int build(int32_t K, const int32_t* rows, const int32_t* cols, int32_t nu
     p->dims.C = (int32_t)C;
     p->dims.nnz = nnz;
     p->dims.nnz_links = (int64_t)links.size();
+    p->dims.nnz_term = (int64_t)p->rowptr[C];          // rows [0, C) are the term layers
     *out = p;
     return ONTOVAE_OK;
 }
