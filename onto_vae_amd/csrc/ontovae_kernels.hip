@@ -1656,23 +1656,6 @@ __global__ __launch_bounds__(256) void ov_wgrad_cb_kernel(const OvWgradArgs a) {
     ov_wgrad_cb_body(a, blockIdx.x, threadIdx.x, sh_k0, sh_len, sh_ord);
 }
 
-// Backward term chain and the gene rows of the weight gradient in ONE launch.  The chain occupies only ldb / BT
-// workgroups (32 CUs at batch 128) for its whole, latency-bound duration, and the gene rows of the weight gradient
-// (everything it needs is final once the gene layer's D rows exist) are the largest piece of independent work of the
-// step: workgroups [0, nchain) run the chain, the others are four 256-thread teams of ov_wgrad_cb_body each.  Low
-// workgroup ids are dispatched first, so the chain starts at once and the rest fills the other CUs.
-template <int BT, bool SINGLE>
-__global__ __launch_bounds__(1024) void ov_chain_bwd_wgrad_kernel(const OvChainArgs ca, const OvSteps st, int nchain,
-                                                                const OvWgradArgs wa) {
-    if ((int)blockIdx.x < nchain) {
-        ov_dec_chain_body<BT, true, SINGLE>(ca, st, blockIdx.x);
-        return;
-    }
-    __shared__ int sh[4][3][32];
-    const int team = threadIdx.x >> 8;
-    ov_wgrad_cb_body(wa, ((int)blockIdx.x - nchain) * 4 + team, threadIdx.x & 255, sh[team][0], sh[team][1], sh[team][2]);
-}
-
 // g_k = sum over column blocks of part[cb][k] (fixed order), then AdamW + clamp(0) (vae_model.py:172-176) or the
 // plain gradient; the same for the biases of the rows.
 struct OvFinishArgs {
@@ -1684,6 +1667,7 @@ struct OvFinishArgs {
     // gene layer's partials formed by the backward gene kernel: part is indexed by the link's CSC position q (one
     // coalesced stream per column block), tpart [ncb][nnz_term] holds the term layers' partials by packed position k
     const float* tpart; int64_t nnz_term; const int32_t* csc_row; const int32_t* csc_k;
+    int sel;        // 0: everything; 1: the gene layer's links and biases only; 2: the term layers' only (nnz_term must be set)
 };
 // first / stride: this thread's number and the thread count of the finish part
 __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, const int64_t first, const int64_t stride) {
@@ -1696,28 +1680,33 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
             a.gvals[k] = g;
         }
     };
+    const bool terms = a.sel != 1, genes = a.sel != 2;
     if (a.tpart) {
-        for (int64_t k = first; k < a.nnz_term; k += stride) {
-            float g = 0.f;
-            for (int cb = 0; cb < a.ncb; ++cb) g += a.tpart[(int64_t)cb * a.nnz_term + k];
-            update(k, g);
-        }
+        if (terms)
+            for (int64_t k = first; k < a.nnz_term; k += stride) {
+                float g = 0.f;
+                for (int cb = 0; cb < a.ncb; ++cb) g += a.tpart[(int64_t)cb * a.nnz_term + k];
+                update(k, g);
+            }
         // gene links in CSC order: the partial sums are read as contiguous streams whatever the number of column blocks;
         // what is scattered is one read-modify-write of (w, m, v) per link
-        for (int64_t q = first; q < a.nnz; q += stride) {
-            if (a.csc_row[q] < a.C) continue;                 // a term-to-term link: done above
-            float g = 0.f;
-            for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + q];
-            update(a.csc_k[q], g);
-        }
+        if (genes)
+            for (int64_t q = first; q < a.nnz; q += stride) {
+                if (a.csc_row[q] < a.C) continue;                 // a term-to-term link: done above
+                float g = 0.f;
+                for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + q];
+                update(a.csc_k[q], g);
+            }
     } else {
-        for (int64_t k = first; k < a.nnz; k += stride) {
+        const int64_t kb = terms ? 0 : a.nnz_term, ke = genes ? a.nnz : a.nnz_term;
+        for (int64_t k = kb + first; k < ke; k += stride) {
             float g = 0.f;
             for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
             update(k, g);
         }
     }
-    for (int64_t r = first; r < a.nrows; r += stride) {
+    const int rb = terms ? 0 : a.n_term_rows, re = genes ? a.nrows : a.n_term_rows;
+    for (int64_t r = rb + first; r < re; r += stride) {
         float g = 0.f;
         for (int cb = 0; cb < a.ncb; ++cb) g += a.bpart[(int64_t)cb * a.nrows + r];
         const int node = r < a.n_term_rows ? a.first_term_node + (int)r : a.C + ((int)r - a.n_term_rows);
@@ -1732,6 +1721,22 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
 }
 __global__ __launch_bounds__(256) void ov_wgrad_finish_kernel(const OvFinishArgs a) {
     ov_wgrad_finish_body(a, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+
+// Backward term chain and the gene layer's share of the decoder update in ONE launch.  The chain occupies only ldb / BT
+// workgroups (32 CUs at batch 128) for its whole, latency-bound duration.  Everything the update of the gene layer's
+// weights and biases needs (the partials of the two gene-layer kernels) is final by then and nothing in this launch or
+// after it reads those weights again, so its finish pass (sum of the column blocks' partials, AdamW, clamp) runs on the
+// CUs the chain leaves idle: workgroups [0, nchain) are the chain, the others finish.  Low workgroup ids are dispatched
+// first, so the chain starts at once.
+template <int BT, bool SINGLE>
+__global__ __launch_bounds__(1024) void ov_chain_bwd_finish_kernel(const OvChainArgs ca, const OvSteps st, int nchain,
+                                                                 const OvFinishArgs fa, int fblocks) {
+    if ((int)blockIdx.x < nchain) {
+        ov_dec_chain_body<BT, true, SINGLE>(ca, st, blockIdx.x);
+        return;
+    }
+    ov_wgrad_finish_body(fa, (int64_t)((int)blockIdx.x - nchain) * 1024 + threadIdx.x, (int64_t)fblocks * 1024);
 }
 
 // Two launches of the backward pass that carry unrelated, independent work of the decoder's weight update so that it
@@ -2557,8 +2562,9 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne) {
 #define OV_RIDE_PCT 75      // share of the gene rows whose weight gradient rides in the backward chain's launch (flat from 55 to 100)
 // wg: gene rows of the weight gradient to run in the same launch as the backward chain (fused path only), or NULL;
 // *wg_done tells the caller whether that happened
-static int ov_dec_backward(OvStep& s, const OvWgradArgs* wg = nullptr, bool* wg_done = nullptr) {
-    if (wg_done) *wg_done = false;
+struct OvFinishArgs;
+// fin: finish pass of the gene layer's update to run in the backward chain's launch (fused path only), or NULL
+static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fblocks = 0) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     const int bt = ov_fused_bt(c);
@@ -2593,12 +2599,11 @@ static int ov_dec_backward(OvStep& s, const OvWgradArgs* wg = nullptr, bool* wg_
     const OvChainArgs ca{sb.node, sb.info, sb.chunk0, sb.idx, sb.w, nullptr, s.ws.d, blk, s.ldb, 0, d.C, 0, d.C,
                          (int)OV_DBG((c->flags >> 8) & 7)};
     const int nchain = s.ldb / bt;
-    const int wteams = wg ? ov_cb_grid(wg->ncb, wg->ntiles) : 0;
 #define OV_TB2(BT, SG)                                                                                                \
-    if (wg) {                                                                                                         \
-        if ((rc = ov_set_lds(ov_chain_bwd_wgrad_kernel<BT, SG>, lds))) return rc;                                      \
-        hipLaunchKernelGGL((ov_chain_bwd_wgrad_kernel<BT, SG>), dim3(nchain + (wteams + 3) / 4), dim3(1024), lds, s.st, ca, lv,   \
-                           nchain, *wg);                                                                              \
+    if (fin) {                                                                                                        \
+        if ((rc = ov_set_lds(ov_chain_bwd_finish_kernel<BT, SG>, lds))) return rc;                                     \
+        hipLaunchKernelGGL((ov_chain_bwd_finish_kernel<BT, SG>), dim3(nchain + fblocks), dim3(1024), lds, s.st, ca, lv,           \
+                           nchain, *fin, fblocks);                                                                    \
     } else {                                                                                                          \
         if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, true, SG>, lds))) return rc;                                      \
         hipLaunchKernelGGL((ov_dec_chain_kernel<BT, true, SG>), dim3(nchain), dim3(1024), lds, s.st, ca, lv);          \
@@ -2608,7 +2613,6 @@ static int ov_dec_backward(OvStep& s, const OvWgradArgs* wg = nullptr, bool* wg_
 #undef OV_TB
 #undef OV_TB2
     OV_LAUNCH_CHECK();
-    if (wg && wg_done) *wg_done = true;
     return ONTOVAE_OK;
 }
 
@@ -2931,21 +2935,18 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         if (fused_gw) { s.gw_part = wa.part; s.gw_bpart = wa.bpart; s.gw_rows = wrows; s.gw_row0 = n_term_rows; s.gw_by_q = ncb >= 16; }
     }
     if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
-    const bool wgene_done = fused_gw;
-    if ((rc = ov_dec_backward(s))) return rc;
-    // fork: the decoder's weight gradients need nothing from the encoder backward, and vice versa
-    if ((rc = ov_side_fork(s))) return rc;
-    const hipStream_t sst = ov_side_stream(s);
-    // decoder weight gradients (+ AdamW + clamp): partials of the rows the chain launch did not carry, then the finish
-    // pass.  On the single-stream path both ride in the next two launches (ov_latent_bwd_kernel, ov_da_gemm_kernel).
+    // decoder weight gradients (+ AdamW + clamp): partials of the rows the gene-layer kernels do not cover, then the finish
+    // pass.  On the single-stream path the partials ride in ov_latent_bwd_kernel and the finish pass in two launches: the
+    // gene layer's share in the backward chain's, the term layers' in ov_da_gemm_kernel's.
     float* G_ = c->Gr;
     OvWgradArgs wt = wa;
-    OvFinishArgs fa{};
-    int wteams = 0, fblocks = 0;
+    OvFinishArgs fa{}, fa_gene{};
+    int wteams = 0, fblocks = 0, gblocks = 0;
+    bool ride_fin = false;
     const bool riders2 = wcb && !s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS);
     if (wcb) {
         wt.row0 = 0;
-        wt.nrows_part = wgene_done ? wrows - ride_rows : wrows;
+        wt.nrows_part = fused_gw ? wrows - ride_rows : wrows;
         wt.ntiles = (wt.nrows_part + 31) / 32;
         wteams = ov_cb_grid(wt.ncb, wt.ntiles);
         fblocks = (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 2048);
@@ -2953,15 +2954,29 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                           c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                           G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
                           c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam,
-                          nullptr, 0, nullptr, nullptr};
+                          nullptr, d.nnz_term, nullptr, nullptr, 0};
         if (fused_gw && s.gw_by_q) {
             // term rows: partials by packed position in their own region; gene links: by CSC position in wa.part
             float* tpart = s.ws.wpart + (int64_t)wa.ncb * ((int64_t)d.nnz + d.C + d.G);
             wt.part = tpart;
             wt.nnz = d.nnz_term;
-            fa.tpart = tpart; fa.nnz_term = d.nnz_term; fa.csc_row = c->csc_row; fa.csc_k = c->csc_k;
+            fa.tpart = tpart; fa.csc_row = c->csc_row; fa.csc_k = c->csc_k;
+        }
+        // only while the chain leaves most of the chip idle (<= 128 workgroups): at larger batches the chain's workgroups
+        // fill every CU themselves and 1024-thread riders next to their LDS reservation only stretch the launch
+        ride_fin = fused_gw && s.ldb / std::max(ov_fused_bt(c), 1) <= 128;
+        if (ride_fin) {
+            fa_gene = fa;
+            fa_gene.sel = 1;
+            fa.sel = 2;
+            gblocks = (int)std::min<int64_t>(((int64_t)d.nnz + 1023) / 1024, 448);      // 1024-thread workgroups beside the chain
+            fblocks = (int)std::min<int64_t>(((int64_t)d.nnz_term + d.C + 255) / 256, 2048);
         }
     }
+    if ((rc = ov_dec_backward(s, ride_fin ? &fa_gene : nullptr, gblocks))) return rc;
+    // fork: the decoder's weight gradients need nothing from the encoder backward, and vice versa
+    if ((rc = ov_side_fork(s))) return rc;
+    const hipStream_t sst = ov_side_stream(s);
     if (!riders2) {
         OvProfScope prof(ONTOVAE_PHASE_DEC_WGRAD, sst);
         if (wcb) {
