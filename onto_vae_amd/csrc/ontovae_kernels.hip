@@ -2355,7 +2355,11 @@ static int ov_heads_fwd(OvStep& s) {
         ontovae_set_error("heads GEMM: slab buffer holds %lld floats, [2L, ldb] needs %lld", (long long)s.ws.slab_floats, (long long)one);
         return ONTOVAE_EINVAL;
     }
-    const int S = s.ldb >= 1024 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(3, s.ws.slab_floats / one));
+    // training batches: 3 split-K slabs; inference batches (96 x 128 tiles of the LDS-staged kernel): as many slabs as it takes
+    // to give every CU a workgroup (64 tiles at 1024 columns, 35 -> us), none once the tiles alone fill the chip
+    const int tiles_lds = ((2 * d.L + 95) / 96) * ((s.B + 127) / 128);
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(s.ldb >= 1024 ? std::min(4, 256 / std::max(tiles_lds, 1)) : 3,
+                                                             s.ws.slab_floats / one));
     int kchunk = ((d.L + S - 1) / S + 31) / 32 * 32;
     g.C = s.ws.slab; g.ldc = s.ldb; g.slab_stride = one; g.kchunk = kchunk;
     s.heads_S = (d.L + kchunk - 1) / kchunk;
