@@ -403,6 +403,61 @@ int ontovae_to_feature_major(const float* src, int64_t src_ld, int32_t B, int32_
                              int64_t dst_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The plain VAE sibling: reference class VAE (onto_vae/vae_model.py:913-1140) = Encoder
+ * (onto_vae/modules.py:15-84, any number of [Linear, BatchNorm1d, Dropout, ReLU] blocks, then the mu / log_var heads with
+ * Dropout(z_drop)) + dense Decoder (modules.py:94-154: the same blocks, then a Linear to the genes).  Same conventions as
+ * above: one flat fp32 parameter buffer (ontovae_vae_layout gives the offsets, in floats), moments M / V and gradients Gr in
+ * the same layout, BatchNorm running statistics in bn_state ([running_mean | running_var] per block, offsets *_bn), one
+ * num_batches_tracked counter per block in bn_nbt (encoder blocks first), caller-owned workspace.
+ * -------------------------------------------------------------------------------------------*/
+#define ONTOVAE_VAE_MAX_LAYERS 8
+typedef struct ontovae_vae_dims {
+    int32_t G;                                  /* in_features                      (vae_model.py:934) */
+    int32_t Z;                                  /* latent_dim                       (vae_model.py:937) */
+    int32_t n_enc, n_dec;                       /* blocks of the encoder / decoder (len(layer_dims_enc / _dec)) */
+    int32_t enc[ONTOVAE_VAE_MAX_LAYERS];        /* layer_dims_enc                   (vae_model.py:935) */
+    int32_t dec[ONTOVAE_VAE_MAX_LAYERS];        /* layer_dims_dec                   (vae_model.py:936) */
+} ontovae_vae_dims_t;
+
+typedef struct ontovae_vae_layout {
+    int64_t enc_W[ONTOVAE_VAE_MAX_LAYERS], enc_b[ONTOVAE_VAE_MAX_LAYERS], enc_gamma[ONTOVAE_VAE_MAX_LAYERS], enc_beta[ONTOVAE_VAE_MAX_LAYERS];
+    int64_t dec_W[ONTOVAE_VAE_MAX_LAYERS], dec_b[ONTOVAE_VAE_MAX_LAYERS], dec_gamma[ONTOVAE_VAE_MAX_LAYERS], dec_beta[ONTOVAE_VAE_MAX_LAYERS];
+    int64_t enc_bn[ONTOVAE_VAE_MAX_LAYERS], dec_bn[ONTOVAE_VAE_MAX_LAYERS];   /* into bn_state: running_mean, then running_var */
+    int64_t Wh;      /* [2 Z, enc[-1]]: rows 0..Z-1 encoder.mu.0.weight, rows Z..2Z-1 encoder.logvar.0.weight */
+    int64_t bh;      /* [2 Z] */
+    int64_t Wout;    /* [G, dec[-1]]  decoder.decoder[n_dec].0.weight */
+    int64_t bout;    /* [G] */
+    int64_t total;   /* floats in P */
+    int64_t bn_total;/* floats in bn_state */
+} ontovae_vae_layout_t;
+
+typedef struct ontovae_vae_ctx {
+    ontovae_vae_dims_t dims;
+    float* P; float* M; float* V; float* Gr;    /* M, V: training with apply_update; Gr: apply_update == 0 */
+    float* bn_state;                            /* [bn_total] */
+    int64_t* bn_nbt;                            /* [n_enc + n_dec] */
+    void* workspace; int64_t workspace_bytes;   /* ontovae_vae_workspace_bytes(dims, max_batch), 256-B aligned */
+    int32_t max_batch;
+    float drop, z_drop;                         /* modules.py:48, 58, 63, 123 */
+    uint64_t seed;
+} ontovae_vae_ctx_t;
+
+int ontovae_vae_layout(const ontovae_vae_dims_t* dims, ontovae_vae_layout_t* out);
+int64_t ontovae_vae_workspace_bytes(const ontovae_vae_dims_t* dims, int32_t max_batch);
+/* One body of VAE.train_round (vae_model.py:1026-1037): forward, vae_loss (:995-1004), backward, AdamW (:1101; every
+ * parameter, no masks, no clamp).  Arguments as ontovae_train_step. */
+int ontovae_vae_train_step(const ontovae_vae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
+                           uint64_t rng_offset, float kl_coeff, const ontovae_adamw_t* opt, int32_t apply_update, float* loss_out,
+                           void* stream);
+/* VAE.forward (vae_model.py:979-990) / get_embedding (:965-977) and, with loss_out != NULL, one body of val_round
+ * (:1061-1065).  Outputs (any may be NULL): recon [B, G], mu, log_var, z [B, Z], sample-major; loss_out: device float[3]. */
+int ontovae_vae_forward(const ontovae_vae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
+                        uint64_t rng_offset, int32_t train, float kl_coeff, float* recon, float* mu, float* log_var, float* z_out,
+                        float* loss_out, void* stream);
+/* torch.optim.AdamW.step over the flat buffers with gradients from ctx->Gr (after apply_update == 0). */
+int ontovae_vae_adamw_apply(const ontovae_vae_ctx_t* ctx, const ontovae_adamw_t* opt, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-phase timing with HIP events on the launch stream (measurement only; the reference has no
  * counterpart).  ontovae_profile_begin enables the phases in `phase_mask` (bit = phase id) and
  * reserves `capacity` event pairs per phase; every later launch of an enabled phase is bracketed

@@ -49,6 +49,26 @@ class Ctx(C.Structure):
                 ("sell_fwd", Sell), ("sell_bwd", Sell), ("bf16_ws", C.c_void_p), ("bf16_ws_bytes", C.c_int64)]
 
 
+VAE_MAXL = 8
+
+
+class VaeDims(C.Structure):
+    _fields_ = [("G", C.c_int32), ("Z", C.c_int32), ("n_enc", C.c_int32), ("n_dec", C.c_int32),
+                ("enc", C.c_int32 * VAE_MAXL), ("dec", C.c_int32 * VAE_MAXL)]
+
+
+class VaeLayout(C.Structure):
+    _fields_ = [(n, C.c_int64 * VAE_MAXL) for n in ("enc_W", "enc_b", "enc_gamma", "enc_beta", "dec_W", "dec_b", "dec_gamma", "dec_beta",
+                                                     "enc_bn", "dec_bn")] + \
+               [(n, C.c_int64) for n in ("Wh", "bh", "Wout", "bout", "total", "bn_total")]
+
+
+class VaeCtx(C.Structure):
+    _fields_ = [("dims", VaeDims), ("P", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p), ("Gr", C.c_void_p),
+                ("bn_state", C.c_void_p), ("bn_nbt", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("max_batch", C.c_int32), ("drop", C.c_float), ("z_drop", C.c_float), ("seed", C.c_uint64)]
+
+
 class AdamW(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("decay_mul", "one_m_beta1", "beta2", "one_m_beta2", "step_size", "bc2_sqrt", "eps")]
 
@@ -111,6 +131,10 @@ def lib():
         "ontovae_fdr_bh": [vp, i32, i32, vp, vp, i64, vp],
         "ontovae_fdr_bh_static": [vp, i32, i32, vp, vp],
         "ontovae_to_feature_major": [vp, i64, i32, i32, vp, i64, vp],
+        "ontovae_vae_layout": [C.POINTER(VaeDims), C.POINTER(VaeLayout)],
+        "ontovae_vae_train_step": [C.POINTER(VaeCtx), vp, vp, i32, vp, u64, f32, C.POINTER(AdamW), i32, vp, vp],
+        "ontovae_vae_forward": [C.POINTER(VaeCtx), vp, vp, i32, vp, u64, i32, f32, vp, vp, vp, vp, vp, vp],
+        "ontovae_vae_adamw_apply": [C.POINTER(VaeCtx), C.POINTER(AdamW), vp],
         "ontovae_profile_begin": [C.c_uint32, i32],
         "ontovae_profile_read": [i32, c_f32p, i32, c_i32p],
         "ontovae_profile_end": [],
@@ -124,6 +148,8 @@ def lib():
     for name in ("ontovae_workspace_bytes", "ontovae_bf16_workspace_bytes"):
         getattr(L, name).argtypes = [C.POINTER(Dims), i32]
         getattr(L, name).restype = C.c_int64
+    L.ontovae_vae_workspace_bytes.argtypes = [C.POINTER(VaeDims), i32]
+    L.ontovae_vae_workspace_bytes.restype = C.c_int64
     for name in ("ontovae_wilcoxon_workspace_bytes", "ontovae_fdr_workspace_bytes"):
         getattr(L, name).argtypes = [i32, i32]
         getattr(L, name).restype = C.c_int64
@@ -140,6 +166,7 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals",
             "ontovae_wilcoxon_workspace_bytes", "ontovae_wilcoxon_zsplit", "ontovae_fdr_workspace_bytes", "ontovae_fdr_bh", "ontovae_fdr_bh_static",
             "ontovae_to_feature_major",
+            "ontovae_vae_layout", "ontovae_vae_workspace_bytes", "ontovae_vae_train_step", "ontovae_vae_forward", "ontovae_vae_adamw_apply",
             "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end"]
 
 FLAG_BF16_GEMM = 32

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libontovae_hip.so")
 SOURCES = ["ontovae_plan.cpp", "ontovae_kernels.hip", "ontovae_stats.hip"]
-HEADERS = ["ontovae_internal.h", "ontovae_device.h", "ontovae_gemm.h", os.path.join("..", "..", "include", "ontovae_hip.h")]
+HEADERS = ["ontovae_internal.h", "ontovae_device.h", "ontovae_gemm.h", "ontovae_bf16.h", "ontovae_dense.h", os.path.join("..", "..", "include", "ontovae_hip.h")]
 
 
 def _stale():

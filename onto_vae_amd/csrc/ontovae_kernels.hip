@@ -3418,3 +3418,5 @@ extern "C" int ontovae_dense_to_vals(const float* dense, int64_t ld, const int32
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
+
+#include "ontovae_dense.h"

@@ -495,3 +495,6 @@ class OntoVAE(nn.Module):
             stat, pval = stat[:, ci].contiguous(), pval[:, ci].contiguous()
         qval = dstats.fdr_bh(pval) if P and pval.shape[1] else torch.empty_like(pval)
         return {'stat': stat.cpu().numpy(), 'pval': pval.cpu().numpy(), 'qval': qval.cpu().numpy()}
+
+
+from .dense_vae import VAE  # noqa: E402,F401  (reference vae_model.py:913: the plain VAE lives in the same module)

@@ -262,6 +262,100 @@ def gen_dropout_case(name, counts, G, nu, seed, B, steps, out_dir, drop=0.2, z_d
     return fx, masks
 
 
+def random_vae_state_dict(G, enc, dec, Z, seed):
+    """state_dict of the reference VAE drawn from a numpy seed (nn.Linear ranges, non-trivial BatchNorm state)."""
+    rng = np.random.RandomState(seed)
+    f32 = np.float32
+    sd = {}
+
+    def lin(name, out_f, in_f):
+        b = 1.0 / np.sqrt(in_f)
+        sd[name + ".weight"] = rng.uniform(-b, b, size=(out_f, in_f)).astype(f32)
+        sd[name + ".bias"] = rng.uniform(-b, b, size=(out_f,)).astype(f32)
+
+    def bn(name, n):
+        sd[name + ".weight"] = rng.uniform(0.5, 1.5, size=n).astype(f32)
+        sd[name + ".bias"] = rng.uniform(-0.2, 0.2, size=n).astype(f32)
+        sd[name + ".running_mean"] = rng.uniform(-0.1, 0.1, size=n).astype(f32)
+        sd[name + ".running_var"] = rng.uniform(0.5, 1.5, size=n).astype(f32)
+        sd[name + ".num_batches_tracked"] = np.int64(0)
+
+    cin = G
+    for i, w in enumerate(enc):
+        lin(f"encoder.encoder.{i}.0", w, cin); bn(f"encoder.encoder.{i}.1", w); cin = w
+    lin("encoder.mu.0", Z, cin); lin("encoder.logvar.0", Z, cin)
+    cin = Z
+    for i, w in enumerate(dec):
+        lin(f"decoder.decoder.{i}.0", w, cin); bn(f"decoder.decoder.{i}.1", w); cin = w
+    lin(f"decoder.decoder.{len(dec)}.0", G, cin)
+    return sd
+
+
+def gen_vae_case(name, G, enc, dec, Z, seed, B, steps, out_dir, lr=1e-3, kl_coeff=1e-4):
+    """The plain VAE sibling (reference onto_vae/vae_model.py:913-1140), dropout off, weights and eps injected: forward +
+    loss, gradients of the first step, `steps` train_round bodies, one val_round body, get_embedding."""
+    from onto_vae.vae_model import VAE as RefVAE
+    rng = np.random.RandomState(seed)
+    sd0 = random_vae_state_dict(G, enc, dec, Z, seed + 1)
+    xs = [np.log1p(rng.poisson(0.8, size=(B, G))).astype(np.float32) for _ in range(steps)]
+    epss = [rng.standard_normal(size=(B, Z)).astype(np.float32) for _ in range(steps)]
+    fx = {"G": np.int64(G), "Z": np.int64(Z), "enc": np.array(enc, np.int64), "dec": np.array(dec, np.int64), "lr": np.float64(lr),
+          "kl_coeff": np.float64(kl_coeff), "steps": np.int64(steps)}
+    for k, v in sd0.items():
+        fx[f"sd0/{k}"] = v
+    for s in range(steps):
+        fx[f"x/{s}"], fx[f"eps/{s}"] = xs[s], epss[s]
+
+    def build():
+        torch.manual_seed(0)
+        m = RefVAE(np.zeros((4, G)), layer_dims_enc=list(enc), layer_dims_dec=list(dec), latent_dim=Z, drop=0.0, z_drop=0.0)
+        m.load_state_dict({k: torch.tensor(v) for k, v in sd0.items()})
+        q = EpsQueue()
+        m.reparameterize = q
+        return m, q
+
+    model, epsq = build()
+    model.train()
+    epsq.push(epss[0])
+    with torch.no_grad():
+        x0 = torch.tensor(xs[0])
+        recon, mu, lv = model.forward(x0)
+        run = RunRecorder()
+        loss = model.vae_loss(recon, mu, lv, x0, kl_coeff, mode="train", run=run)
+    fx["fwd/recon"], fx["fwd/mu"], fx["fwd/log_var"] = recon.numpy(), mu.numpy(), lv.numpy()
+    fx["fwd/rec_kl_loss"] = np.array([run["metrics/train/rec_loss"][0], run["metrics/train/kl_loss"][0], float(loss)])
+
+    model, epsq = build()
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    run = RunRecorder()
+    losses = []
+    for s in range(steps):
+        epsq.push(epss[s])
+        losses.append(quiet(model.train_round, [(torch.tensor(xs[s]),)], lr, kl_coeff, opt, run))
+        if s == 0:
+            for n, p_ in model.named_parameters():
+                fx[f"grad0/{n}"] = p_.grad.detach().numpy().copy()
+    fx["train/loss"] = np.array(losses)
+    fx["train/rec"] = np.array(run["metrics/train/rec_loss"])
+    fx["train/kl"] = np.array(run["metrics/train/kl_loss"])
+    for k, v in model.state_dict().items():
+        fx[f"sdT/{k}"] = v.detach().numpy().copy()
+    xv = np.log1p(rng.poisson(0.8, size=(9, G))).astype(np.float32)
+    ev = rng.standard_normal(size=(9, Z)).astype(np.float32)
+    epsq.push(ev)
+    runv = RunRecorder()
+    vloss = quiet(model.val_round, [(torch.tensor(xv),)], kl_coeff, runv)
+    fx["val/x"], fx["val/eps"] = xv, ev
+    fx["val/rec_kl_loss"] = np.array([runv["metrics/val/rec_loss"][0], runv["metrics/val/kl_loss"][0], vloss])
+    model.eval()
+    epsq.push(ev)
+    with torch.no_grad():
+        fx["val/embedding"] = model.get_embedding(torch.tensor(xv)).numpy()
+    path = os.path.join(out_dir, f"{name}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: VAE G={G} enc={enc} Z={Z} dec={dec} steps={steps} -> {path} ({os.path.getsize(path)/1e3:.0f} kB)")
+
+
 def gen_loader(out_dir):
     """FastTensorDataLoader batch order under torch.manual_seed (fast_data_loader.py:31-43) and
     the train/val split (vae_model.py:233-235)."""
@@ -318,5 +412,7 @@ if __name__ == "__main__":
     check_oracle(fx, masks)
     fx, masks = gen_case("g1_nu1", counts=[5, 4], G=31, nu=1, seed=303, B=5, steps=4, out_dir=a.out, n_inf=3)
     check_oracle(fx, masks)
+    gen_vae_case("vae_small", G=150, enc=[40], dec=[48], Z=12, seed=505, B=24, steps=5, out_dir=a.out)
+    gen_vae_case("vae_deep", G=90, enc=[36, 20], dec=[16, 28], Z=7, seed=606, B=17, steps=4, out_dir=a.out)
     gen_dropout_case("g1_drop", counts=[6, 9, 7], G=120, nu=3, seed=404, B=24, steps=4, out_dir=a.out)
     gen_loader(a.out)
