@@ -902,6 +902,9 @@ __device__ __forceinline__ void ov_rec_load(OvRec& r, int sl, int lane, const in
     const int base = c0 * 512 + lane;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+#ifdef OV_CHAIN_HALF
+        if (e >= 4) { r.id[e] = r.id[e - 4]; r.w[e] = r.w[e - 4]; continue; }
+#endif
         r.id[e] = sidx[base + e * 64];
         r.w[e] = sw[base + e * 64];
     }
@@ -915,9 +918,19 @@ struct OvChainArgs {
     const float* sw; const float* sbias;
     float* glob; const float* inblk;
     int ldb, in0, in1, out0, out1, dbg;
+    int nrep;      // workgroups per column group (see ov_chain_replicas)
 };
 template <int BT, bool BWD, bool SINGLE>
-__device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const OvSteps& st, const int block) {
+__device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const OvSteps& st, const int wg) {
+    // Workgroup -> (column group, replica).  A column group's panel lives in ONE workgroup's LDS, and handing its C rows to
+    // the feature-major matrix in HBM is C separate 16-B writes from that CU, about 1.7 clocks each: 7.4 of the kernel's 30 us
+    // at C = 9000, whatever the batch size.  While the launch leaves CUs idle (32 column groups at batch 128), nrep workgroups
+    // walk the SAME chain for a column group (the records come from the L2 they share, the arithmetic is free) and each
+    // writes only the rows of every nrep-th slice.  Ids are dealt round-robin to the 8 XCDs; an XCD's workgroups take adjacent
+    // column groups and all replicas of a group sit on one XCD.  ldb / BT is a multiple of 8.
+    const int gpx = ca.ldb / BT / 8;                    // column groups per XCD
+    const int block = (wg & 7) * gpx + (wg >> 3) % gpx;
+    const int rep = (wg >> 3) / gpx;
     const int32_t* __restrict__ snode = ca.snode;
     const int32_t* __restrict__ sinfo = ca.sinfo;
     const int32_t* __restrict__ chunk0 = ca.chunk0;
@@ -1023,22 +1036,18 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
                             for (int j = 0; j < BT; ++j) acc[j] += cur.bias;
                         }
                         ov_stv<BT>(ov_panel + (int64_t)cur.node * BT, acc);
+                        // and to the feature-major matrix in HBM, for the gene layer and the weight gradient: issued here, the
+                        // 16-B pieces drain under the rest of the chain (as one pass at the end they were 7.5 of the kernel's 28 us)
+                        if (!(dbg & 8) && sl % ca.nrep == rep) ov_stv<BT>(glob + (int64_t)cur.node * ldb + b0, acc);
                     }
                 }
                 if (!(dbg & 1)) request(rec[t], q + OV_CHAIN_DEPTH);     // this ring slot's next record
             }
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // epilogue: results LDS -> HBM (feature-major), for the gene layer and the weight gradient
-    if (!(dbg & 1))
-    for (int p = out0 + threadIdx.x; p < out1; p += 1024) {
-        float v[BT];
-        ov_ldv<BT>(ov_panel + (int64_t)p * BT, v);
-        ov_stv<BT>(glob + (int64_t)p * ldb + b0, v);
-    }
+    // No epilogue: every row the chain produces went to HBM when its writer lane stored it.  (Backward: rows without term
+    // children have no writer; the gene backward kernel stores those feature-major itself.)
+    (void)out0; (void)out1;
 }
 
 template <int BT, bool BWD, bool SINGLE>
@@ -1537,8 +1546,10 @@ __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __re
     }
     if (node < C) {
         // dblk: column-group-major [ldb / 4][C][4], what a workgroup of the backward chain loads in one piece
+        // feature-major: final for the nodes the backward chain does not touch (no term children), input of the latent
+        // backward and the weight gradient
+        *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = acc;
         if (dblk) *reinterpret_cast<f32x4*>(dblk + ((int64_t)(map.cb * 8 + (lane & 7)) * C + node) * 4) = acc;
-        else *reinterpret_cast<f32x4*>(d + (int64_t)node * ldb + col0 + s4) = acc;
     }
 }
 
@@ -2471,6 +2482,9 @@ static int ov_sell_refresh(OvStep& s, hipStream_t st) {
     return ONTOVAE_OK;
 }
 
+// replicas of every column group's chain workgroup (ov_dec_chain_body): fill the CUs the launch would leave idle, at most 4 (8 buy nothing more)
+static int ov_chain_replicas(int nchain, int most = 4) { return std::max(1, std::min(most, 256 / std::max(nchain, 1))); }
+
 // refreshed = the packed weight copies were already refreshed for this pass (on the side stream, joined)
 static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     const ontovae_ctx_t* c = s.c;
@@ -2493,11 +2507,12 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     ov_make_steps(f, &lv);
     const size_t lds = (size_t)d.C * bt * sizeof(float);
     OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
+    const int nrep = ov_chain_replicas(s.ldb / bt);
     const OvChainArgs ca{f.node, f.info, f.chunk0, f.idx, f.w, f.bias, s.ws.act, nullptr, s.ldb, d.C - d.L, d.C, 0, d.C - d.L,
-                         (int)OV_DBG((c->flags >> 8) & 7)};
+                         (int)OV_DBG((c->flags >> 8) & 15), nrep};
 #define OV_TF2(BT, SG)                                                                                                \
     if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false, SG>, lds))) return rc;                                         \
-    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false, SG>), dim3(s.ldb / BT), dim3(1024), lds, s.st, ca, lv)
+    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false, SG>), dim3(s.ldb / BT * nrep), dim3(1024), lds, s.st, ca, lv)
 #define OV_TF(BT) do { if (f.all_single_chunk) { OV_TF2(BT, true); } else { OV_TF2(BT, false); } } while (0)
     if (bt == 4) { OV_TF(4); } else if (bt == 2) { OV_TF(2); } else { OV_TF(1); }
 #undef OV_TF
@@ -2600,9 +2615,10 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
     ov_make_steps(sb, &lv);
     const size_t lds = (size_t)d.C * bt * sizeof(float);
     OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
+    const int nrep = ov_chain_replicas(s.ldb / bt);
     const OvChainArgs ca{sb.node, sb.info, sb.chunk0, sb.idx, sb.w, nullptr, s.ws.d, blk, s.ldb, 0, d.C, 0, d.C,
-                         (int)OV_DBG((c->flags >> 8) & 7)};
-    const int nchain = s.ldb / bt;
+                         (int)OV_DBG((c->flags >> 8) & 15), nrep};
+    const int nchain = s.ldb / bt * nrep;
 #define OV_TB2(BT, SG)                                                                                                \
     if (fin) {                                                                                                        \
         if ((rc = ov_set_lds(ov_chain_bwd_finish_kernel<BT, SG>, lds))) return rc;                                     \

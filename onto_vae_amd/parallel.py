@@ -18,6 +18,40 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    def wait(self):
+        pass
+
+
+def _stream_ordered(group):
+    """nccl (RCCL) collectives are ordered on streams and may be left outstanding.  Any other backend (gloo: the CPU and
+    2-process tests) gets host tensors: gloo's own handling of device tensors was seen to stall when two processes share one
+    GPU, so device buffers are staged through the host here, one completed collective at a time."""
+    return dist.get_backend(group) == "nccl"
+
+
+def all_reduce(t, group=None, async_op=False):
+    if _stream_ordered(group):
+        return dist.all_reduce(t, group=group, async_op=async_op) or _Done()
+    if t.is_cuda:
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return _Done()
+
+
+def all_gather_into_tensor(out, t, group=None):
+    if _stream_ordered(group) or not t.is_cuda:
+        dist.all_gather_into_tensor(out, t, group=group)
+        return
+    h = t.detach().cpu()
+    ho = torch.empty(out.shape, dtype=out.dtype)
+    dist.all_gather_into_tensor(ho, h, group=group)
+    out.copy_(ho)
+
+
 def shard_bounds(B, world, rank):
     """Rows [start, start+size) of a global batch of B rows owned by `rank` (sizes differ by <= 1)."""
     base, rem = divmod(int(B), int(world))
@@ -146,7 +180,7 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
 
     lbuf = loss_out if not reduce_loss else st.lloc        # phase 1 writes {rec, kl, rec + kl_coeff kl} of this rank's rows
     e.train_step_dp(0, xl, il, B, el, kl_coeff, st.stats, st.bstats, lbuf, off)
-    dist.all_gather_into_tensor(st.stats_all, st.stats_send, group=group)
+    all_gather_into_tensor(st.stats_all, st.stats_send, group=group)
 
     e.train_step_dp(16 + world, xl, il, B, el, kl_coeff, st.stats_all, st.bstats, lbuf, off)
 
@@ -154,20 +188,20 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
     if use_gathered_dh(B, world, L, e.plan.G):
         if os.environ.get("ONTOVAE_DP_TWO_EXCHANGES") == "1":
             # all-reduce of the BatchNorm-backward sums, then all-gather of dh
-            dist.all_reduce(st.bstats, group=group)
+            all_reduce(st.bstats, group=group)
             e.dp_bn_bwd(size, B, st.bstats, off, st.send, st.blm)
-            dist.all_gather_into_tensor(st.gathered, st.send, group=group)
+            all_gather_into_tensor(st.gathered, st.send, group=group)
             gathered, rstride = st.gathered, st.rstride
         else:
             # one exchange: all-gather of [dy | xhat | local sums]; every rank adds the sums in rank order and forms dh of
             # all columns itself (one small collective less on the critical path)
             e.dp_pack_dy(size, st.send2, st.blm)
-            dist.all_gather_into_tensor(st.gathered2, st.send2, group=group)
+            all_gather_into_tensor(st.gathered2, st.send2, group=group)
             e.dp_dh_global(B, st.sizes, st.blm, st.gathered2, st.rstride2)
             gathered, rstride = st.gathered2, st.rstride2
         # issued after the all-gather (collectives of one communicator run in order, and dW0 waits for the gather
         # only); it then runs under the dW0 kernel
-        h_early = dist.all_reduce(e.Gr[int(lay.Wh):int(lay.total)], group=group, async_op=True)
+        h_early = all_reduce(e.Gr[int(lay.Wh):int(lay.total)], group=group, async_op=True)
         if xidx is None:
             e.dw0_global(e._x(x, None)[0], None, st.colmap32, world, st.blm, gathered, rstride, hyper)
         else:
@@ -175,9 +209,9 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
         h_early.wait()
         e.adamw_apply_range(hyper, int(lay.b0), int(lay.total))
     else:
-        dist.all_reduce(st.bstats, group=group)
+        all_reduce(st.bstats, group=group)
         late, early = grad_buckets(lay)
-        h_early = dist.all_reduce(e.Gr[early[0]:early[1]], group=group, async_op=True)     # under the dW0 products
+        h_early = all_reduce(e.Gr[early[0]:early[1]], group=group, async_op=True)     # under the dW0 products
         # W0's gradient (28.8 MB at GO-BP scale, the bulk) in contiguous ROW panels: panel p's all-reduce is issued right
         # after its product and runs under the products of the panels after it (the collective's stream waits only for what
         # is on the compute stream when it is issued); what stays exposed is the last panel's exchange
@@ -186,8 +220,8 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
         handles = []
         for l0, l1 in w0_row_panels(L, world):
             e.dw0_rows(xl, il, l0, l1)
-            handles.append((l0, l1, dist.all_reduce(e.Gr[int(lay.W0) + l0 * G:int(lay.W0) + l1 * G], group=group, async_op=True)))
-        h_small = dist.all_reduce(e.Gr[int(lay.b0):late[1]], group=group, async_op=True)   # b0, gamma, beta
+            handles.append((l0, l1, all_reduce(e.Gr[int(lay.W0) + l0 * G:int(lay.W0) + l1 * G], group=group, async_op=True)))
+        h_small = all_reduce(e.Gr[int(lay.b0):late[1]], group=group, async_op=True)   # b0, gamma, beta
         for l0, l1, h in handles:
             h.wait()
             e.adamw_apply_range(hyper, int(lay.W0) + l0 * G, int(lay.W0) + l1 * G)
@@ -195,5 +229,5 @@ def dp_train_step(model, x, xidx, eps, kl_coeff, opt, loss_out, group=None, redu
         h_early.wait()
         e.adamw_apply_range(hyper, int(lay.b0), int(lay.total))
     if reduce_loss:
-        dist.all_reduce(st.lloc, group=group)
+        all_reduce(st.lloc, group=group)
         loss_out.copy_(st.lloc)

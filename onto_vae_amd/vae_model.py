@@ -226,7 +226,8 @@ class OntoVAE(nn.Module):
                 self._engine.train_step(x, xidx, self._eps(B), kl_coeff, opt.next_hyper(), losses[n])
             n += 1
         if self._dp_world() > 1 and n > 0:
-            torch.distributed.all_reduce(losses[:n])        # the ranks' partial sums of the whole epoch, once
+            from .parallel import all_reduce
+            all_reduce(losses[:n])                          # the ranks' partial sums of the whole epoch, once
         return self._collect(losses, n, 'train', run) / len(dataloader)
 
     def val_round(self, dataloader, kl_coeff, run=None):

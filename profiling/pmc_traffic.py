@@ -2,14 +2,14 @@
 profiles/pmc_traffic.json: HBM-side bytes per launch for every kernel and for bench.py's phases.
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KB; on gfx950
 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRITE_SIZE is taken as is.
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
+    python profiling/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
 """
 import csv, collections, json, sys
 
 PHASE_OF = {"ov_dw0_kernel": "dw0", "ov_gemm_lds_kernel": "enc_gemm", "ov_gene_cb_kernel": "dec_fwd_gene",
-            "ov_bwd_gene_cb_kernel": "dec_bwd_gene", "ov_chain_bwd_wgrad_kernel": "dec_bwd",
+            "ov_bwd_gene_cb_kernel": "dec_bwd_gene", "ov_chain_bwd_finish_kernel": "dec_bwd",
             "ov_dec_chain_kernel": "dec_fwd_terms", "ov_latent_bwd_kernel": "latent_bwd", "ov_da_gemm_kernel": "da_gemm",
-            "ov_dwh_bn_kernel": "dwh", "ov_bn_fwd_kernel": "bn_fwd", "ov_reparam_kernel": "reparam"}
+            "ov_dwh_bn_kernel": "dwh", "ov_bn_fwd_kernel": "bn_fwd", "ov_reparam_kernel": "reparam", "ov_gemm_kernel<1, 1, 4, 4": "heads"}
 
 
 def per_kernel(path, counter):
