@@ -292,9 +292,7 @@ def test_dp_allreduce_form_gobp_syn_global_8192():
     (ontovae_train_step_dp phases 0 / 1 with all-gathered statistics / 2, SUM of the flat gradient buffers, flat AdamW):
     must land where the single-device step on the global batch lands (held to the oracle above), replicas identical.
     The same exchange through onto_vae_amd.parallel.dp_train_step and real collectives runs in
-    test_gpu_parity.py::test_dp_two_processes_one_gpu (medium model) and, in the gathered form at full size, below; two
-    PROCESSES at 4096 rows each on one shared GPU are not run: host-staged gloo copies next to these kernels stalled for
-    minutes on the test box."""
+    test_gpu_parity.py::test_dp_two_processes_one_gpu (medium model) and, in both forms at full size, in two processes below."""
     from onto_vae_amd.parallel import use_gathered_dh
     from onto_vae_amd.vae_model import FusedAdamW
     for world in (2, 4, 8):
@@ -338,11 +336,11 @@ def test_dp_allreduce_form_gobp_syn_global_8192():
     assert (diff > 1e-6 + 1e-4 * np.abs(want[keep])).mean() <= 0.01 and diff.max() <= 2 * lr
 
 
-@pytest.mark.parametrize("B,form", [(1024, "gathered")])
+@pytest.mark.parametrize("B,form", [(1024, "gathered"), (8192, "allreduce")])
 def test_dp_two_processes_gobp_syn_heuristic_forms(tmp_path, B, form):
     """onto_vae_amd.parallel.dp_train_step on the full-size model, two processes on GPU 0 over gloo, exchange form chosen by
-    use_gathered_dh itself: global batch 1024 -> all-gathered dh and dW0 over 8 chunks of the K loop on every rank.  One
-    step must land where the single-process step on the global batch lands (itself held to the oracle above), replicas
+    use_gathered_dh itself: global batch 1024 -> all-gathered dh and dW0 over 8 chunks of the K loop on every rank; global
+    batch 8192 (configs[2]) -> all-reduce of the first layer's gradient in row panels.  One step must land where the single-process step on the global batch lands (itself held to the oracle above), replicas
     bitwise identical."""
     from onto_vae_amd.parallel import use_gathered_dh
     from onto_vae_amd.vae_model import FusedAdamW
