@@ -89,6 +89,11 @@ int ontovae_plan_export(const ontovae_plan_t* plan, int32_t* rowptr, int32_t* co
 /* csc_split[p], p in [0, C): index of the first gene entry of CSC column p; the entries before it
  * are the term-to-term links of that column (rows ascend and term nodes precede gene nodes). */
 int ontovae_plan_csc_split(const ontovae_plan_t* plan, int32_t* csc_split);
+/* Packed position k (index into dec_vals and into every buffer laid out like it) of the link at CSR position j, [nnz].
+ * Term layers: k = j.  Gene layer: k orders the links by (panel node, gene), the order of the gene part of the CSC lists
+ * (csc_k of those entries ascends by 1), so that the backward gene kernel reads weights and writes gradient partials in
+ * contiguous runs; rowptr / colidx stay indexed by j. */
+int ontovae_plan_row_k(const ontovae_plan_t* plan, int32_t* row_k);
 /* Dense coordinates of every packed entry, in vals order: entry k is
  * decoder.decoder[layer[k]][0].weight[row[k], col[k]] of the reference's state_dict. */
 int ontovae_plan_entry_coords(const ontovae_plan_t* plan, int32_t* layer, int32_t* row, int32_t* col);
@@ -167,6 +172,7 @@ typedef struct ontovae_ctx {
     const int32_t* csc_row;
     const int32_t* csc_k;
     const int32_t* csc_split;  /* [C] first GENE entry of each CSC column (term rows sort first) */
+    const int32_t* row_k;      /* [nnz] packed position of CSR position j (ontovae_plan_row_k) */
     /* level schedule (host arrays, K+1 entries each) */
     const int32_t* level_begin;
     const int32_t* level_end;

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ONTOVAE_HIP_LIB") or os.path.join(HERE, "libontovae_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -42,7 +42,7 @@ class Ctx(C.Structure):
                 ("P", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p), ("Gr", C.c_void_p),
                 ("bn_rmean", C.c_void_p), ("bn_rvar", C.c_void_p), ("bn_nbt", C.c_void_p),
                 ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("cscptr", C.c_void_p), ("csc_row", C.c_void_p),
-                ("csc_k", C.c_void_p), ("csc_split", C.c_void_p),
+                ("csc_k", C.c_void_p), ("csc_split", C.c_void_p), ("row_k", C.c_void_p),
                 ("level_begin", c_i32p), ("level_end", c_i32p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_batch", C.c_int32),
                 ("drop", C.c_float), ("z_drop", C.c_float), ("seed", C.c_uint64), ("flags", C.c_uint32),
@@ -103,6 +103,7 @@ def lib():
         "ontovae_plan_export": [vp, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "ontovae_plan_entry_coords": [vp, c_i32p, c_i32p, c_i32p],
         "ontovae_plan_csc_split": [vp, c_i32p],
+        "ontovae_plan_row_k": [vp, c_i32p],
         "ontovae_plan_sell_sizes": [vp, i32, c_i32p, c_i32p, c_i32p, c_i32p],
         "ontovae_plan_sell_export": [vp, i32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "ontovae_plan_layer_node0": [vp, i32, c_i32p, c_i32p],
@@ -159,7 +160,7 @@ def lib():
 
 EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", "ontovae_plan_create_from_links",
             "ontovae_plan_destroy", "ontovae_plan_dims", "ontovae_plan_levels", "ontovae_plan_export",
-            "ontovae_plan_entry_coords", "ontovae_plan_csc_split", "ontovae_plan_sell_sizes", "ontovae_plan_sell_export", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
+            "ontovae_plan_entry_coords", "ontovae_plan_csc_split", "ontovae_plan_row_k", "ontovae_plan_sell_sizes", "ontovae_plan_sell_export", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
             "ontovae_workspace_bytes", "ontovae_bf16_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
             "ontovae_adamw_apply", "ontovae_adamw_apply_range", "ontovae_dp_bn_bwd", "ontovae_dw0_rows", "ontovae_dw0_global", "ontovae_dp_pack_dy", "ontovae_dp_dh_global", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
             "ontovae_encode_pre", "ontovae_pass_data_perturbed",

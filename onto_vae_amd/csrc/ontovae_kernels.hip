@@ -116,7 +116,8 @@ struct OvWs {
     float *slab, *xhat, *a, *mulv, *epsw, *act, *d, *dblk, *dmulv, *da, *dh;
     float *bn_mean, *bn_invstd, *bn_bwd_local;
     float *rec_part, *kl_part;
-    float *wpart;              // [ldb / 32][nnz + C + G + nnz_term] weight-gradient partials of the 32-column blocks
+    float *wpart;              // [ldb / 32][nnz + C + G] weight-gradient partials of the 32-column blocks
+    float *wgene;              // [nnz - nnz_term] gene-layer weights in CSR order, refreshed from P at the start of every pass
     int64_t slab_floats;
     int npart_max;
 };
@@ -166,7 +167,8 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs
     w.bn_bwd_local = take(2 * L);
     w.rec_part = take(npart);
     w.kl_part = take(npart);
-    w.wpart = take((ldb / 32) * ((int64_t)d.nnz + C + G + d.nnz_term));
+    w.wpart = take((ldb / 32) * ((int64_t)d.nnz + C + G));
+    w.wgene = take((int64_t)d.nnz - d.nnz_term);
     w.slab_floats = slab;
     w.npart_max = (int)npart;
     if (ws) *ws = w;
@@ -468,11 +470,13 @@ struct OvRefresh {
     const int32_t* kf; float* wf; int nf;
     const int32_t* nodef; float* biasf; int nbf;
     const int32_t* kb; float* wb; int nb;
+    const int32_t* kg; float* wg; int ng;      // gene layer: weights in CSR order (what the forward gene kernels walk) <- packed order
 };
 __device__ __forceinline__ void ov_sell_refresh_part(const OvRefresh& r, int first, int stride) {
     for (int i = first; i < r.nf; i += stride) { const int k = r.kf[i]; r.wf[i] = k >= 0 ? r.vals[k] : 0.f; }
     for (int i = first; i < r.nbf; i += stride) { const int n = r.nodef[i]; r.biasf[i] = n >= 0 ? r.bias[n] : 0.f; }
     for (int i = first; i < r.nb; i += stride) { const int k = r.kb[i]; r.wb[i] = k >= 0 ? r.vals[k] : 0.f; }
+    for (int i = first; i < r.ng; i += stride) r.wg[i] = r.vals[r.kg[i]];
 }
 
 __global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mulv, const float* __restrict__ eps,
@@ -1054,6 +1058,13 @@ template <int BT, bool BWD, bool SINGLE>
 __global__ __launch_bounds__(1024) void ov_dec_chain_kernel(const OvChainArgs ca, const OvSteps st) {
     ov_dec_chain_body<BT, BWD, SINGLE>(ca, st, blockIdx.x);
 }
+// forward chain + riders: workgroups beyond nchain refresh the CSR-ordered copy of the gene layer's weights, which the next
+// launch (the gene layer) reads and nothing in this one does
+template <int BT, bool SINGLE>
+__global__ __launch_bounds__(1024) void ov_chain_fwd_refresh_kernel(const OvChainArgs ca, const OvSteps st, int nchain, const OvRefresh rf) {
+    if ((int)blockIdx.x < nchain) { ov_dec_chain_body<BT, false, SINGLE>(ca, st, blockIdx.x); return; }
+    ov_sell_refresh_part(rf, ((int)blockIdx.x - nchain) * 1024 + threadIdx.x, ((int)gridDim.x - nchain) * 1024);
+}
 
 // Cooperative entry prefetch for the row-per-wave gather kernels: the 64 lanes load up to 64
 // (index, weight) pairs of the row in one coalesced pass; v_readlane then hands them out as scalars,
@@ -1354,12 +1365,13 @@ __device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const
 //   part[k] = sum over the block's columns of ACT[p, cols] * D[g, cols]    (weight gradient partial of link k)
 // so the weight gradient of the gene layer needs no gathers of its own (it used to re-read one ACT row per link in the
 // launches of the backward chain and of the latent backward).  The dot is reduced over the group's 8 lanes with 3 DPP
-// adds; lane s keeps entry s of the batch of 8 and stores it at its link's CSC position: the group's 8 lanes write 32
-// contiguous bytes, a node's list one contiguous run (the finish pass walks the links in CSC order too).
+// adds; lane s keeps entry s of the batch of 8 and stores it at its link's packed position, which ascends by 1 along the
+// list (ontovae_plan_row_k): the group's 8 lanes write 32 contiguous bytes, a node's list one contiguous run, and the
+// weights are read the same way.
 __device__ __forceinline__ void ov_gather_grp_wgrad(f32x4& acc, int k0, int len, const int32_t* __restrict__ rowidx,
                                                     const int32_t* __restrict__ kidx, const float* __restrict__ vals,
                                                     const float* __restrict__ srccol, int ldb, int lane, const f32x4 aseg,
-                                                    float* __restrict__ part, const bool by_q) {
+                                                    float* __restrict__ part) {
     const int s = lane & 7;
     int maxlen = len;                    // wave maximum of len
 #pragma unroll
@@ -1370,10 +1382,9 @@ __device__ __forceinline__ void ov_gather_grp_wgrad(f32x4& acc, int k0, int len,
         r = len > 0 ? rowidx[k0 + ee] : 0;
         w = 0.f;
         k = -1;
-        if (e < len) {          // k: where the link's partial goes, its CSC position (by_q) or its packed position
-            const int kk = kidx[k0 + e];
-            w = vals[kk];
-            k = by_q ? k0 + e : kk;
+        if (e < len) {          // k: the link's packed position (ascending by 1 along the list: ontovae_plan_row_k)
+            k = kidx[k0 + e];
+            w = vals[k];
         }
     };
     int cur_r, nxt_r = 0, cur_k, nxt_k = -1;
@@ -1524,7 +1535,7 @@ __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __re
                                                             const float* __restrict__ vals, float* __restrict__ d,
                                                             float* __restrict__ dblk, int C, int ldb, int ncb, int ntiles,
                                                             const float* __restrict__ act, float* __restrict__ wpart, int64_t nnz,
-                                                            int wpart_by_q) {
+                                                            int unused_) {
     __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
     const OvCbMap map = ov_cb_map(blockIdx.x, ncb, ntiles);
     if (map.tile >= ntiles) return;
@@ -1540,7 +1551,7 @@ __global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __re
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (wpart) {
         const f32x4 aseg = *reinterpret_cast<const f32x4*>(act + (int64_t)min(node, C - 1) * ldb + col0 + s4);
-        ov_gather_grp_wgrad(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz, wpart_by_q != 0);
+        ov_gather_grp_wgrad(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz);
     } else {
         ov_gather_grp<true, OV_GENE_BWD_U>(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane);
     }
@@ -1601,7 +1612,7 @@ __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restri
 // blocks are pinned to XCDs like the other gene-layer kernels, so the panel columns a workgroup gathers stay in its
 // L2.  ov_wgrad_finish_kernel adds the blocks' partials in a fixed order and applies AdamW + clamp.
 struct OvWgradArgs {
-    const int32_t* rowptr; const int32_t* colidx; const float* act; const float* d;
+    const int32_t* rowptr; const int32_t* colidx; const int32_t* row_k; const float* act; const float* d;
     float* part; float* bpart;
     int64_t nnz;
     int row0, nrows_part, nrows;      // this launch covers rows [row0, row0 + nrows_part) of the nrows rows
@@ -1638,11 +1649,17 @@ __device__ __forceinline__ void ov_wgrad_cb_body(const OvWgradArgs& a, int wg, i
     for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
     maxlen = __builtin_amdgcn_readfirstlane(maxlen);
     const float* actcol = a.act + col0 + s4;
-    float* prow = a.part + (int64_t)map.cb * a.nnz + k0;
-    auto fetch = [&](int e) { return len > 0 ? a.colidx[k0 + max(min(e, len - 1), 0)] : 0; };
-    int cur_c = fetch(s), nxt_c = 0;
+    float* pblk = a.part + (int64_t)map.cb * a.nnz;
+    // the link's column node and its packed position (where its partial goes)
+    auto fetch = [&](int e, int& cnode, int& kpos) {
+        const int j = k0 + max(min(e, len - 1), 0);
+        cnode = len > 0 ? a.colidx[j] : 0;
+        kpos = len > 0 ? a.row_k[j] : 0;
+    };
+    int cur_c, cur_k, nxt_c = 0, nxt_k = 0;
+    fetch(s, cur_c, cur_k);
     for (int b0 = 0; b0 < maxlen; b0 += 8) {
-        if (b0 + 8 < maxlen) nxt_c = fetch(b0 + 8 + s);
+        if (b0 + 8 < maxlen) fetch(b0 + 8 + s, nxt_c, nxt_k);
         f32x4 v[8];
 #define OV_WG_LOAD(I) v[I] = *reinterpret_cast<const f32x4*>(actcol + (int64_t)ov_grp_bcast<I>(cur_c) * a.ldb);
         OV_WG_LOAD(0) OV_WG_LOAD(1) OV_WG_LOAD(2) OV_WG_LOAD(3) OV_WG_LOAD(4) OV_WG_LOAD(5) OV_WG_LOAD(6) OV_WG_LOAD(7)
@@ -1657,8 +1674,8 @@ __device__ __forceinline__ void ov_wgrad_cb_body(const OvWgradArgs& a, int wg, i
             t = ov_group_sum<3>(t);                                   // xor 1, xor 2, half mirror: every lane of the group has the total
             mine = s == i ? t : mine;
         }
-        if (row_on && b0 + s < len) prow[b0 + s] = mine;
-        cur_c = nxt_c;
+        if (row_on && b0 + s < len) pblk[cur_k] = mine;
+        cur_c = nxt_c; cur_k = nxt_k;
     }
 }
 
@@ -1675,9 +1692,7 @@ struct OvFinishArgs {
     float* vals; float* mvals; float* vvals; float* gvals;
     float* bias; float* mbias; float* vbias; float* gbias;
     int apply_update; OvAdam adam;
-    // gene layer's partials formed by the backward gene kernel: part is indexed by the link's CSC position q (one
-    // coalesced stream per column block), tpart [ncb][nnz_term] holds the term layers' partials by packed position k
-    const float* tpart; int64_t nnz_term; const int32_t* csc_row; const int32_t* csc_k;
+    int64_t nnz_term;
     int sel;        // 0: everything; 1: the gene layer's links and biases only; 2: the term layers' only (nnz_term must be set)
 };
 // first / stride: this thread's number and the thread count of the finish part
@@ -1692,29 +1707,11 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
         }
     };
     const bool terms = a.sel != 1, genes = a.sel != 2;
-    if (a.tpart) {
-        if (terms)
-            for (int64_t k = first; k < a.nnz_term; k += stride) {
-                float g = 0.f;
-                for (int cb = 0; cb < a.ncb; ++cb) g += a.tpart[(int64_t)cb * a.nnz_term + k];
-                update(k, g);
-            }
-        // gene links in CSC order: the partial sums are read as contiguous streams whatever the number of column blocks;
-        // what is scattered is one read-modify-write of (w, m, v) per link
-        if (genes)
-            for (int64_t q = first; q < a.nnz; q += stride) {
-                if (a.csc_row[q] < a.C) continue;                 // a term-to-term link: done above
-                float g = 0.f;
-                for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + q];
-                update(a.csc_k[q], g);
-            }
-    } else {
-        const int64_t kb = terms ? 0 : a.nnz_term, ke = genes ? a.nnz : a.nnz_term;
-        for (int64_t k = kb + first; k < ke; k += stride) {
-            float g = 0.f;
-            for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
-            update(k, g);
-        }
+    const int64_t kb = terms ? 0 : a.nnz_term, ke = genes ? a.nnz : a.nnz_term;
+    for (int64_t k = kb + first; k < ke; k += stride) {
+        float g = 0.f;
+        for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
+        update(k, g);
     }
     const int rb = terms ? 0 : a.n_term_rows, re = genes ? a.nrows : a.n_term_rows;
     for (int64_t r = rb + first; r < re; r += stride) {
@@ -1787,7 +1784,7 @@ __global__ __launch_bounds__(256) void ov_dwh_bn_kernel(const OvGemm g, int gx, 
 #define OV_WGRAD_U 16      // row dots in flight per wave (64 % OV_WGRAD_U == 0)
 #define OV_WGRAD_NB 2      // 64-column blocks of the batch per trip
 __global__ __launch_bounds__(256) void ov_dec_wgrad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                                          const float* __restrict__ act, const float* __restrict__ d,
+                                                          const int32_t* __restrict__ row_k, const float* __restrict__ act, const float* __restrict__ d,
                                                           float* __restrict__ vals, float* __restrict__ mvals,
                                                           float* __restrict__ vvals, float* __restrict__ gvals,
                                                           float* __restrict__ bias, float* __restrict__ mbias,
@@ -1808,7 +1805,7 @@ __global__ __launch_bounds__(256) void ov_dec_wgrad_kernel(const int32_t* __rest
         const int cnt = min(64, k1 - kb);
         // one coalesced index load per 64 entries; lanes beyond cnt repeat the last entry (its row is re-read from L1)
         const int my_c = colidx[kb + min(lane, cnt - 1)];
-        const int k = kb + lane;
+        const int k = row_k[kb + min(lane, cnt - 1)];      // packed position of the lane's link
         float w = 0.f, m = 0.f, v = 0.f;
         if (apply_update && lane < cnt) { w = vals[k]; m = mvals[k]; v = vvals[k]; }     // lands under the dots
         float mine = 0.f;
@@ -2083,7 +2080,7 @@ static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
         ontovae_set_error("ctx: bad dims G=%d L=%d C=%d K=%d nu=%d", d.G, d.L, d.C, d.K, d.nu);
         return ONTOVAE_EINVAL;
     }
-    if (!c->P || !c->rowptr || !c->colidx || !c->cscptr || !c->csc_row || !c->csc_k || !c->csc_split || !c->level_begin || !c->level_end ||
+    if (!c->P || !c->rowptr || !c->colidx || !c->cscptr || !c->csc_row || !c->csc_k || !c->csc_split || !c->row_k || !c->level_begin || !c->level_end ||
         !c->workspace || !c->bn_rmean || !c->bn_rvar || !c->bn_nbt) {
         ontovae_set_error("ctx: a required pointer is NULL");
         return ONTOVAE_EINVAL;
@@ -2217,7 +2214,7 @@ struct OvStep {
     bool want_xT;            // bf16 variant: the encoder's conversion pass also writes the transposed copy of x (training steps)
     // training, column-block kernels: the gene layer's weight gradient is formed inside the gene-layer kernels themselves
     // (bias partials in the forward kernel, link partials in the backward kernel); NULL = not wanted
-    float* gw_part; float* gw_bpart; int gw_rows, gw_row0; bool gw_by_q;
+    float* gw_part; float* gw_bpart; int gw_rows, gw_row0;
 };
 
 // Independent branches of a step run on a library-owned second stream, forked from and joined back into
@@ -2382,17 +2379,33 @@ static int ov_heads_fwd(OvStep& s) {
 }
 
 static int ov_fused_bt(const ontovae_ctx_t* c);
-// arguments of the SELL weight refresh; blocks = 0 if this model does not use the fused chain
-static int ov_refresh_args(const ontovae_ctx_t* c, OvRefresh* r) {
+#define OV_CHAIN_MAX_LDB 2048
+// the forward pass of this step runs the fused term chain: the gene layer's copy is then refreshed by riders of that launch
+// (25 us on a fraction of the chip) instead of in front of it
+static bool ov_gene_refresh_rides(const OvStep& s) {
+    const int bt = ov_fused_bt(s.c);
+    return bt != 0 && s.ldb / bt <= 128;        // the chain and its replicas leave half of the CUs to riders
+}
+static void ov_gene_refresh_args(const OvStep& s, OvRefresh* r) {
+    const ontovae_ctx_t* c = s.c;
+    r->vals = c->P + c->lay.dec_vals;
+    r->kg = c->row_k + c->dims.nnz_term; r->wg = s.ws.wgene; r->ng = (int)(c->dims.nnz - c->dims.nnz_term);
+}
+// arguments of the refresh of the re-ordered weight copies: SELL order of the term layers (only if this model uses the fused
+// chain), CSR order of the gene layer (every forward gene kernel reads it; here unless it rides in the chain's launch)
+static int ov_refresh_args(const OvStep& s, OvRefresh* r) {
+    const ontovae_ctx_t* c = s.c;
     *r = OvRefresh{};
-    if (ov_fused_bt(c) == 0) return 0;
-    const ontovae_sell_t& f = c->sell_fwd;
-    const ontovae_sell_t& b = c->sell_bwd;
     r->vals = c->P + c->lay.dec_vals; r->bias = c->P + c->lay.dec_bias;
-    r->kf = f.k; r->wf = f.w; r->nf = f.n_chunks * 512;
-    r->nodef = f.node; r->biasf = f.bias; r->nbf = f.n_slices * 64;
-    r->kb = b.k; r->wb = b.w; r->nb = b.n_chunks * 512;
-    return std::min(512, (std::max(r->nf, r->nb) + 255) / 256);
+    if (ov_fused_bt(c) != 0) {
+        const ontovae_sell_t& f = c->sell_fwd;
+        const ontovae_sell_t& b = c->sell_bwd;
+        r->kf = f.k; r->wf = f.w; r->nf = f.n_chunks * 512;
+        r->nodef = f.node; r->biasf = f.bias; r->nbf = f.n_slices * 64;
+        r->kb = b.k; r->wb = b.w; r->nb = b.n_chunks * 512;
+    }
+    if (!ov_gene_refresh_rides(s)) ov_gene_refresh_args(s, r);
+    return std::min(512, (std::max(std::max(r->nf, r->nb), r->ng) + 255) / 256);
 }
 
 // with_refresh: the launch also refreshes the packed term-layer weights (callers then skip ov_sell_refresh)
@@ -2406,7 +2419,7 @@ static int ov_reparam(OvStep& s, const float* eps, int train, uint64_t rng_off, 
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, n >= (1 << 20) ? std::min<int64_t>(4096, npart) : 512);
     float* zrows = s.ws.act + (int64_t)(d.C - d.L) * s.ldb;
     OvRefresh rf{};
-    const int rblocks = with_refresh ? ov_refresh_args(c, &rf) : 0;
+    const int rblocks = with_refresh ? ov_refresh_args(s, &rf) : 0;
     OvProfScope prof(ONTOVAE_PHASE_REPARAM, s.st);
     // eps is kept for the backward pass only
     hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks + rblocks), dim3(256), 0, s.st, s.ws.mulv, eps, train ? s.ws.epsw : nullptr, zrows, s.ws.kl_part,
@@ -2424,7 +2437,8 @@ static int ov_dec_fwd_level(OvStep& s, int nb, int ne, float* rec_out, int64_t r
     const ontovae_dims_t& d = c->dims;
     if (ne <= nb) return ONTOVAE_OK;
     dim3 grid((ne - nb + 3) / 4, s.nchunk);
-    const float* vals = c->P + c->lay.dec_vals;
+    // the gene rows' links are walked in CSR order: their weights come from the CSR-ordered copy (ov_refresh_args)
+    const float* vals = GENE ? s.ws.wgene - d.nnz_term : c->P + c->lay.dec_vals;
     const float* bias = c->P + c->lay.dec_bias;
     OvProfScope prof(GENE ? ONTOVAE_PHASE_DEC_FWD_GENE : ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
     if (GENE == 0 && s.fm_out) {          // ov_fm_fused(s) held: see ontovae_pass_data_perturbed
@@ -2446,7 +2460,6 @@ static int ov_dec_fwd_level(OvStep& s, int nb, int ne, float* rec_out, int64_t r
     return ONTOVAE_OK;
 }
 
-#define OV_CHAIN_MAX_LDB 2048
 // batch columns per workgroup of the fused term-level kernels: the [C][BT] fp32 panel must fit LDS
 static int ov_fused_bt(const ontovae_ctx_t* c) {
     const ontovae_dims_t& d = c->dims;
@@ -2474,7 +2487,7 @@ static int ov_set_lds(KernelT kernel, size_t bytes) {
 // SELL weight copies <- parameter buffer; called once per pass before the first chain kernel
 static int ov_sell_refresh(OvStep& s, hipStream_t st) {
     OvRefresh rf{};
-    const int blocks = ov_refresh_args(s.c, &rf);
+    const int blocks = ov_refresh_args(s, &rf);
     if (blocks == 0) return ONTOVAE_OK;
     OvProfScope prof(ONTOVAE_PHASE_SELL_REFRESH, st);
     hipLaunchKernelGGL(ov_sell_refresh_kernel, dim3(blocks), dim3(256), 0, st, rf);
@@ -2482,8 +2495,10 @@ static int ov_sell_refresh(OvStep& s, hipStream_t st) {
     return ONTOVAE_OK;
 }
 
-// replicas of every column group's chain workgroup (ov_dec_chain_body): fill the CUs the launch would leave idle, at most 4 (8 buy nothing more)
-static int ov_chain_replicas(int nchain, int most = 4) { return std::max(1, std::min(most, 256 / std::max(nchain, 1))); }
+// replicas of every column group's chain workgroup (ov_dec_chain_body): up to half of the CUs (the riders of the chain
+// launches take the rest; every workgroup of such a launch reserves the panel's LDS, so it has a CU to itself), at most 4
+// (8 buy nothing more)
+static int ov_chain_replicas(int nchain) { return std::max(1, std::min(4, 128 / std::max(nchain, 1))); }
 
 // refreshed = the packed weight copies were already refreshed for this pass (on the side stream, joined)
 static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
@@ -2493,15 +2508,13 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     // of latency-bound workgroups; from 2048 columns on one launch per level over the whole batch is faster
     // (B = 4096: 121 us against 203 us; B = 1024: 75 against 51)
     const int bt = s.ldb >= OV_CHAIN_MAX_LDB ? 0 : ov_fused_bt(c);
+    int rc;
+    if (!refreshed && (rc = ov_sell_refresh(s, s.st))) return rc;      // also the gene layer's CSR-ordered copy, whatever the path
     if (bt == 0) {
-        for (int lvl = 1; lvl < d.K; ++lvl) {
-            int rc = ov_dec_fwd_level<0>(s, c->level_begin[lvl], c->level_end[lvl], nullptr, 0);
-            if (rc) return rc;
-        }
+        for (int lvl = 1; lvl < d.K; ++lvl)
+            if ((rc = ov_dec_fwd_level<0>(s, c->level_begin[lvl], c->level_end[lvl], nullptr, 0))) return rc;
         return ONTOVAE_OK;
     }
-    int rc;
-    if (!refreshed && (rc = ov_sell_refresh(s, s.st))) return rc;
     const ontovae_sell_t& f = c->sell_fwd;
     OvSteps lv;
     ov_make_steps(f, &lv);
@@ -2510,9 +2523,13 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     const int nrep = ov_chain_replicas(s.ldb / bt);
     const OvChainArgs ca{f.node, f.info, f.chunk0, f.idx, f.w, f.bias, s.ws.act, nullptr, s.ldb, d.C - d.L, d.C, 0, d.C - d.L,
                          (int)OV_DBG((c->flags >> 8) & 15), nrep};
+    OvRefresh rg{};
+    ov_gene_refresh_args(s, &rg);
+    const int nchain = s.ldb / bt * nrep;
+    const int rblocks = ov_gene_refresh_rides(s) ? std::max(1, std::min(96, (rg.ng + 4095) / 4096)) : 0;      // else done with the SELL copies
 #define OV_TF2(BT, SG)                                                                                                \
-    if ((rc = ov_set_lds(ov_dec_chain_kernel<BT, false, SG>, lds))) return rc;                                         \
-    hipLaunchKernelGGL((ov_dec_chain_kernel<BT, false, SG>), dim3(s.ldb / BT * nrep), dim3(1024), lds, s.st, ca, lv)
+    if ((rc = ov_set_lds(ov_chain_fwd_refresh_kernel<BT, SG>, lds))) return rc;                                        \
+    hipLaunchKernelGGL((ov_chain_fwd_refresh_kernel<BT, SG>), dim3(nchain + rblocks), dim3(1024), lds, s.st, ca, lv, nchain, rg)
 #define OV_TF(BT) do { if (f.all_single_chunk) { OV_TF2(BT, true); } else { OV_TF2(BT, false); } } while (0)
     if (bt == 4) { OV_TF(4); } else if (bt == 2) { OV_TF(2); } else { OV_TF(1); }
 #undef OV_TF
@@ -2530,7 +2547,7 @@ static int ov_dec_gene(OvStep& s, float* rec_out, int64_t rec_ld) {
     if (MODE == 1) tiled = tiled && ov_al16(s.x) && (s.xld % 4 == 0);
     if (MODE == 2) tiled = tiled && ov_al16(rec_out) && (rec_ld % 4 == 0);
     if (!tiled) return ov_dec_fwd_level<MODE>(s, d.C, d.C + d.G, rec_out, rec_ld);
-    const float* vals = c->P + c->lay.dec_vals;
+    const float* vals = s.ws.wgene - d.nnz_term;            // CSR-ordered copy of the gene layer's weights (ov_refresh_args)
     const float* bias = c->P + c->lay.dec_bias;
     OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_GENE, s.st);
     if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
@@ -2600,7 +2617,7 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
         const int ncb = s.ldb / 32, ntiles = (d.C + 31) / 32;
         if (bt == 4) blk = s.ws.dblk;           // the chain's workgroups take 4 columns each: hand them contiguous pieces
         hipLaunchKernelGGL(ov_bwd_gene_cb_kernel, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row,
-                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles, s.ws.act, s.gw_part, (int64_t)d.nnz, s.gw_by_q ? 1 : 0);
+                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles, s.ws.act, s.gw_part, (int64_t)d.nnz, 0);
         OV_LAUNCH_CHECK();
     } else {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
@@ -2659,7 +2676,7 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->fm_out = nullptr;
     s->fm_ld = 0;
     s->want_xT = false;
-    s->gw_part = nullptr; s->gw_bpart = nullptr; s->gw_rows = 0; s->gw_row0 = 0; s->gw_by_q = false;
+    s->gw_part = nullptr; s->gw_bpart = nullptr; s->gw_rows = 0; s->gw_row0 = 0;
     return ONTOVAE_OK;
 }
 
@@ -2947,12 +2964,9 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     if (wcb) {
         const int ncb = s.ldb / 32;
         ride_rows = fused_gw ? d.G : 0;          // gene rows done elsewhere
-        wa = OvWgradArgs{c->rowptr, c->colidx, s.ws.act, s.ws.d, s.ws.wpart, s.ws.wpart + (int64_t)ncb * d.nnz, (int64_t)d.nnz,
+        wa = OvWgradArgs{c->rowptr, c->colidx, c->row_k, s.ws.act, s.ws.d, s.ws.wpart, s.ws.wpart + (int64_t)ncb * d.nnz, (int64_t)d.nnz,
                          wrows - ride_rows, ride_rows, wrows, 0, n_term_rows, d.C, s.ldb, ncb, (ride_rows + 31) / 32};
-        // Where a link's partial is stored: at its packed position k (a scattered 4-B store per link and column block, a
-        // coalesced finish pass) or at its CSC position (contiguous stores, ONE scattered read-modify-write of (w, m, v) per
-        // link in the finish pass, ~22 us at GO-BP scale whatever the batch).  Measured cross-over: 16 column blocks.
-        if (fused_gw) { s.gw_part = wa.part; s.gw_bpart = wa.bpart; s.gw_rows = wrows; s.gw_row0 = n_term_rows; s.gw_by_q = ncb >= 16; }
+        if (fused_gw) { s.gw_part = wa.part; s.gw_bpart = wa.bpart; s.gw_rows = wrows; s.gw_row0 = n_term_rows; }
     }
     if ((rc = ov_dec_gene<1>(s, nullptr, 0))) return rc;
     // decoder weight gradients (+ AdamW + clamp): partials of the rows the gene-layer kernels do not cover, then the finish
@@ -2974,14 +2988,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                           c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                           G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
                           c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam,
-                          nullptr, d.nnz_term, nullptr, nullptr, 0};
-        if (fused_gw && s.gw_by_q) {
-            // term rows: partials by packed position in their own region; gene links: by CSC position in wa.part
-            float* tpart = s.ws.wpart + (int64_t)wa.ncb * ((int64_t)d.nnz + d.C + d.G);
-            wt.part = tpart;
-            wt.nnz = d.nnz_term;
-            fa.tpart = tpart; fa.csc_row = c->csc_row; fa.csc_k = c->csc_k;
-        }
+                          d.nnz_term, 0};
         // only while the chain leaves most of the chip idle (<= 128 workgroups): at larger batches the chain's workgroups
         // fill every CU themselves and 1024-thread riders next to their LDS reservation only stretch the launch
         ride_fin = fused_gw && s.ldb / std::max(ov_fused_bt(c), 1) <= 128;
@@ -3005,7 +3012,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
             hipLaunchKernelGGL(ov_wgrad_finish_kernel, dim3(fblocks), dim3(256), 0, sst, fa);
             OV_LAUNCH_CHECK();
         } else {
-            hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((wrows + 3) / 4), dim3(256), 0, sst, c->rowptr, c->colidx, s.ws.act, s.ws.d,
+            hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((wrows + 3) / 4), dim3(256), 0, sst, c->rowptr, c->colidx, c->row_k, s.ws.act, s.ws.d,
                                c->P + lay.dec_vals, c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                                G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
                                c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, wrows, 0, n_term_rows, d.C, s.ldb,

@@ -33,6 +33,7 @@ struct ontovae_plan {
     std::vector<int32_t> level_begin;  // K+1 entries (level K = genes)
     std::vector<int32_t> level_end;
     std::vector<int32_t> rowptr, colidx, cscptr, csc_row, csc_k;
+    std::vector<int32_t> row_k;        // packed position k of CSR position j (identity for the term layers)
     std::vector<int32_t> e_layer, e_row, e_col;   // dense coordinates per packed entry
     std::vector<int64_t> layer_k0;     // first packed entry of each layer (K+1)
     // level-scheduled SELL-64 form of the term layers, [0] forward (CSR rows), [1] backward (term part
@@ -284,6 +285,29 @@ static int build(int32_t K, const int32_t* rows, const int32_t* cols, int32_t nu
                 p->csc_k[pos] = q;
             }
     }
+    // Packed position k of every link (= its place in dec_vals and in every buffer laid out like it).  Term layers: the
+    // CSR position.  Gene layer: ordered by (panel node, gene), the order in which the gene part of the CSC lists walks the
+    // links: the backward gene kernel, which has the D rows of a node's genes in registers and forms the weight gradient
+    // of those links there, then reads the weights and writes the gradient partials as contiguous runs per node (by CSR
+    // position every one of them was a scattered 4-B access into a 1.9 MB array at GO-BP scale).  The forward gene kernel
+    // reads its weights through row_k instead.
+    {
+        const int32_t nnz_term = p->rowptr[C];
+        p->row_k.resize(nnz);
+        for (int32_t j = 0; j < nnz_term; ++j) p->row_k[j] = j;
+        int32_t next = nnz_term;
+        for (int64_t c = 0; c < C; ++c)
+            for (int32_t q = p->cscptr[c]; q < p->cscptr[c + 1]; ++q)
+                if (p->csc_row[q] >= C) {
+                    p->row_k[p->csc_k[q]] = next;
+                    p->csc_k[q] = next++;
+                }
+        std::vector<int32_t> el(p->e_layer), er(p->e_row), ec(p->e_col);
+        for (int64_t j = nnz_term; j < nnz; ++j) {
+            const int32_t k2 = p->row_k[j];
+            p->e_layer[k2] = el[j]; p->e_row[k2] = er[j]; p->e_col[k2] = ec[j];
+        }
+    }
     p->dims.C = (int32_t)C;
     p->dims.K = K;
     build_sell(p, 0);
@@ -365,6 +389,12 @@ extern "C" int ontovae_plan_export(const ontovae_plan_t* plan, int32_t* rowptr, 
     cp(cscptr, plan->cscptr);
     cp(csc_row, plan->csc_row);
     cp(csc_k, plan->csc_k);
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_row_k(const ontovae_plan_t* plan, int32_t* row_k) {
+    if (!plan || !row_k) return ONTOVAE_EINVAL;
+    if (!plan->row_k.empty()) std::memcpy(row_k, plan->row_k.data(), sizeof(int32_t) * plan->row_k.size());
     return ONTOVAE_OK;
 }
 

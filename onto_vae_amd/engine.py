@@ -159,7 +159,7 @@ class Engine:
             dv["bias"] = torch.zeros(max(sd["n_slices"], 1) * 64, dtype=torch.float32, device=dev)
             self._sell.append(dv)
         self._idx = dict(rowptr=t(p.rowptr), colidx=t(p.colidx), cscptr=t(p.cscptr), csc_row=t(p.csc_row),
-                         csc_k=t(p.csc_k), csc_split=t(p.csc_split), er=t(p.entry_row), ec=t(p.entry_col))
+                         csc_k=t(p.csc_k), csc_split=t(p.csc_split), row_k=t(p.row_k), er=t(p.entry_row), ec=t(p.entry_col))
         self._ctx = None
 
     def to(self, device):
@@ -222,6 +222,7 @@ class Engine:
             c.rowptr, c.colidx = _ptr(i["rowptr"]), _ptr(i["colidx"])
             c.cscptr, c.csc_row, c.csc_k = _ptr(i["cscptr"]), _ptr(i["csc_row"]), _ptr(i["csc_k"])
             c.csc_split = _ptr(i["csc_split"])
+            c.row_k = _ptr(i["row_k"])
             c.level_begin = self.plan.level_begin.ctypes.data_as(_lib.c_i32p)
             c.level_end = self.plan.level_end.ctypes.data_as(_lib.c_i32p)
             for name, sd, dev in (("sell_fwd", self.plan.sell[0], self._sell[0]), ("sell_bwd", self.plan.sell[1], self._sell[1])):

@@ -65,6 +65,9 @@ class MaskPlan:
                                          _i32p(self.csc_row), _i32p(self.csc_k)), "plan export")
         self.csc_split = np.zeros(max(self.C, 1), dtype=np.int32)
         _lib.check(L.ontovae_plan_csc_split(handle, _i32p(self.csc_split)), "plan csc split")
+        # packed position k of CSR position j: identity for the term layers, (panel node, gene) order for the gene layer
+        self.row_k = np.zeros(n, dtype=np.int32)
+        _lib.check(L.ontovae_plan_row_k(handle, _i32p(self.row_k)), "plan row_k")
         self.sell = [self._export_sell(d) for d in (0, 1)]
         self.entry_layer = np.zeros(n, dtype=np.int32)
         self.entry_row = np.zeros(n, dtype=np.int32)

@@ -40,4 +40,4 @@ for dbg in [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0
         _lib.check(L.ontovae_profile_read(ph, buf, 64 * n, C.byref(cnt)), "profile_read")
         out[name] = sum(buf[i] for i in range(cnt.value)) / n * 1e3
     L.ontovae_profile_end()
-    print(f"dbg={dbg}: chain fwd {out['dec_fwd_terms']:.1f} us, chain bwd {out['dec_bwd']:.1f} us, total {sum(out.values()):.1f} us", flush=True)
+    print({k: round(v, 1) for k, v in out.items() if v > 0}); print(f"dbg={dbg}: chain fwd {out['dec_fwd_terms']:.1f} us, chain bwd {out['dec_bwd']:.1f} us, total {sum(out.values()):.1f} us", flush=True)

@@ -18,27 +18,37 @@ def check_plan(masks, nu):
     for i, m in enumerate(exp):
         assert plan.layer_shapes[i] == m.shape
         assert np.array_equal(plan.unpack_mask(i), m.astype(np.uint8)), f"layer {i}"
-    # entry coordinates address exactly the ones of the expanded masks, row-major within a layer
+    # entry coordinates address exactly the ones of the expanded masks: row-major within a term layer, column-major
+    # (by panel node, then gene) within the gene layer
     for i, m in enumerate(exp):
         k0, k1 = plan.layer_entries[i]
         r, c = plan.entry_row[k0:k1], plan.entry_col[k0:k1]
-        rr, cc = np.nonzero(m)
+        if i < plan.K - 1:
+            rr, cc = np.nonzero(m)
+        else:
+            cc, rr = np.nonzero(m.T)
         assert np.array_equal(r, rr) and np.array_equal(c, cc)
-    # CSR node mapping: row node = level block + row, col node = C - in_i + col
+    # CSR node mapping (positions j): row node = level block + row, col node = C - in_i + col; row_k[j] = packed position
     C = plan.C
+    assert sorted(plan.row_k[:plan.nnz].tolist()) == list(range(plan.nnz))
+    nnz_term = int(plan.rowptr[C])
+    assert np.array_equal(plan.row_k[:nnz_term], np.arange(nnz_term))
+    rows = np.repeat(np.arange(C + plan.G), np.diff(plan.rowptr))
     for i in range(plan.K):
         k0, k1 = plan.layer_entries[i]
         n0, nout = plan.layer_nodes[i]
         cin = plan.layer_shapes[i][1]
-        rows_from_ptr = np.repeat(np.arange(C + plan.G), np.diff(plan.rowptr))[k0:k1]
-        assert np.array_equal(rows_from_ptr, n0 + plan.entry_row[k0:k1])
-        assert np.array_equal(plan.colidx[k0:k1], C - cin + plan.entry_col[k0:k1])
-    # CSC is the transpose: same (row, col, k) triples
-    rows = np.repeat(np.arange(C + plan.G), np.diff(plan.rowptr))
+        js = np.nonzero((rows >= n0) & (rows < n0 + nout))[0]
+        assert sorted(plan.row_k[js].tolist()) == list(range(k0, k1))
+        assert np.array_equal(rows[js], n0 + plan.entry_row[plan.row_k[js]])
+        assert np.array_equal(plan.colidx[js], C - cin + plan.entry_col[plan.row_k[js]])
+    # CSC is the transpose: same (row, col, k) triples; the gene part of the lists walks k in steps of 1
     csc_cols = np.repeat(np.arange(C), np.diff(plan.cscptr))
-    a = set(zip(rows.tolist(), plan.colidx[:plan.nnz].tolist(), range(plan.nnz)))
+    a = set(zip(rows.tolist(), plan.colidx[:plan.nnz].tolist(), plan.row_k[:plan.nnz].tolist()))
     b = set(zip(plan.csc_row[:plan.nnz].tolist(), csc_cols.tolist(), plan.csc_k[:plan.nnz].tolist()))
     assert a == b
+    gene_k = plan.csc_k[:plan.nnz][plan.csc_row[:plan.nnz] >= C]
+    assert np.array_equal(gene_k, np.arange(nnz_term, plan.nnz))
     for p in range(C):  # rows ascend inside a column
         seg = plan.csc_row[plan.cscptr[p]:plan.cscptr[p + 1]]
         assert np.all(np.diff(seg) > 0)
@@ -80,7 +90,7 @@ def test_pack_from_links_equals_dense():
     layer, row, col = (np.concatenate([a, a[:5]]) for a in (layer, row, col))
     a = MaskPlan(masks, 2)
     b = MaskPlan(neuronnum=2, links=(layer, row, col), shapes=[m.shape for m in masks])
-    for f in ("rowptr", "colidx", "cscptr", "csc_row", "csc_k", "entry_layer", "entry_row", "entry_col"):
+    for f in ("rowptr", "colidx", "cscptr", "csc_row", "csc_k", "row_k", "entry_layer", "entry_row", "entry_col"):
         assert np.array_equal(getattr(a, f), getattr(b, f)), f
 
 
