@@ -207,12 +207,13 @@ def infer_bench(a, model, dev, world, rank, steps=None, warmup=None):
     return {
         "metric": "inference samples/sec (GO-BP OntoVAE get_pathway_activities)", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[3]: GOBP-syn get_pathway_activities ('act' output, [rows, 3000] fp32), "
                                f"batches of {B} rows from {rows} HBM-resident rows per GPU", "batch_per_gpu": B,
                    "dataset_rows": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
         "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                     "frac": t_mfma / sec, "traffic": None, "kernel": "whole step (encoder GEMM dominates)",
+                     "frac": t_mfma / sec, "traffic": None, "kernel": "whole step (encoder GEMM dominates)" +
+                     (" against the fp32 MFMA peak; the encoder product itself runs on bf16 MFMA" if DTYPE == "bf16" else ""),
                      "algorithmic_flops": flops}}
 
 

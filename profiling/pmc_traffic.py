@@ -8,7 +8,7 @@ import csv, collections, json, sys
 
 PHASE_OF = {"ov_dw0_kernel": "dw0", "ov_gemm_lds_kernel": "enc_gemm", "ov_gene_cb_kernel": "dec_fwd_gene",
             "ov_bwd_gene_cb_kernel": "dec_bwd_gene", "ov_chain_bwd_finish_kernel": "dec_bwd",
-            "ov_dec_chain_kernel": "dec_fwd_terms", "ov_latent_bwd_kernel": "latent_bwd", "ov_da_gemm_kernel": "da_gemm",
+            "ov_dec_chain_kernel": "dec_fwd_terms", "ov_chain_fwd_refresh_kernel": "dec_fwd_terms", "ov_latent_bwd_kernel": "latent_bwd", "ov_da_gemm_kernel": "da_gemm",
             "ov_dwh_bn_kernel": "dwh", "ov_bn_fwd_kernel": "bn_fwd", "ov_reparam_kernel": "reparam", "ov_gemm_kernel<1, 1, 4, 4": "heads"}
 
 
@@ -36,6 +36,16 @@ def main():
         for stem, phase in PHASE_OF.items():
             if short.startswith(stem) and phase not in out:
                 out[phase] = rd + wr
+    # keys this script does not measure (the screen's Wilcoxon kernel, a pass of its own: profiles/r01) are carried over
+    prev = {}
+    for path in ("profiles/r01/pmc_traffic.json", "profiles/pmc_traffic.json"):
+        try:
+            prev.update({k: v for k, v in json.load(open(path)).items() if k == "wilcoxon"})
+        except (OSError, ValueError):
+            pass
+    if "wilcoxon" in prev:
+        out["wilcoxon"] = prev["wilcoxon"]
+        out["_note"] += "; 'wilcoxon' from the round-1 passes (profiles/r01/r01_v8_pmc_wilcoxon_*.csv; that kernel has not changed since)"
     json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
     for k, v in out["kernels"].items():
         print(f"{k[:60]:60s} read {v['read_bytes']/1e6:8.1f} MB write {v['write_bytes']/1e6:8.1f} MB")
