@@ -180,6 +180,7 @@ typedef struct ontovae_ctx {
     void* workspace;
     int64_t workspace_bytes;
     int32_t max_batch;
+    int32_t max_train_batch;   /* rows a TRAINING pass may take (ontovae_workspace_bytes_split); 0: max_batch */
     /* dropout (train mode only) and eps generation */
     float drop;                /* Encoder dropout p            (modules.py:48) */
     float z_drop;              /* latent dropout p             (modules.py:58, 63) */
@@ -209,6 +210,12 @@ typedef struct ontovae_ctx {
                                            hand-offs cost about what the overlap gains) */
 
 int64_t ontovae_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch);
+/* The buffers only a training pass touches (weight-gradient partials: batch / 32 copies of the packed decoder, the backward's
+ * matrices) sized by max_train_batch <= max_batch, everything else by max_batch: a model that trains at 128 rows and
+ * serves 16384-row inference batches then needs 2.7 GB of workspace at GO-BP scale instead of 4.5.  ctx->max_train_batch
+ * must be set to the same value; training entry points (ontovae_train_step*, ontovae_dw0_*, ontovae_dp_*,
+ * ontovae_forward with train != 0) refuse more rows. */
+int64_t ontovae_workspace_bytes_split(const ontovae_dims_t* dims, int32_t max_batch, int32_t max_train_batch);
 int64_t ontovae_bf16_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch);
 
 /* AdamW hyper-parameters of one step, pre-folded on the host in double like torch does

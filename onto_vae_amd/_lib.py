@@ -44,7 +44,7 @@ class Ctx(C.Structure):
                 ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("cscptr", C.c_void_p), ("csc_row", C.c_void_p),
                 ("csc_k", C.c_void_p), ("csc_split", C.c_void_p), ("row_k", C.c_void_p),
                 ("level_begin", c_i32p), ("level_end", c_i32p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_batch", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_batch", C.c_int32), ("max_train_batch", C.c_int32),
                 ("drop", C.c_float), ("z_drop", C.c_float), ("seed", C.c_uint64), ("flags", C.c_uint32),
                 ("sell_fwd", Sell), ("sell_bwd", Sell), ("bf16_ws", C.c_void_p), ("bf16_ws_bytes", C.c_int64)]
 
@@ -149,6 +149,8 @@ def lib():
     for name in ("ontovae_workspace_bytes", "ontovae_bf16_workspace_bytes"):
         getattr(L, name).argtypes = [C.POINTER(Dims), i32]
         getattr(L, name).restype = C.c_int64
+    L.ontovae_workspace_bytes_split.argtypes = [C.POINTER(Dims), i32, i32]
+    L.ontovae_workspace_bytes_split.restype = C.c_int64
     L.ontovae_vae_workspace_bytes.argtypes = [C.POINTER(VaeDims), i32]
     L.ontovae_vae_workspace_bytes.restype = C.c_int64
     for name in ("ontovae_wilcoxon_workspace_bytes", "ontovae_fdr_workspace_bytes"):
@@ -161,7 +163,7 @@ def lib():
 EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", "ontovae_plan_create_from_links",
             "ontovae_plan_destroy", "ontovae_plan_dims", "ontovae_plan_levels", "ontovae_plan_export",
             "ontovae_plan_entry_coords", "ontovae_plan_csc_split", "ontovae_plan_row_k", "ontovae_plan_sell_sizes", "ontovae_plan_sell_export", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
-            "ontovae_workspace_bytes", "ontovae_bf16_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
+            "ontovae_workspace_bytes", "ontovae_workspace_bytes_split", "ontovae_bf16_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
             "ontovae_adamw_apply", "ontovae_adamw_apply_range", "ontovae_dp_bn_bwd", "ontovae_dw0_rows", "ontovae_dw0_global", "ontovae_dp_pack_dy", "ontovae_dp_dh_global", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
             "ontovae_encode_pre", "ontovae_pass_data_perturbed",
             "ontovae_compose_order", "ontovae_gather_rows", "ontovae_vals_to_dense", "ontovae_dense_to_vals",

@@ -135,8 +135,16 @@ static int ov_enc_splitk(int L, int B, int G) {
     return std::max(1, std::min(std::min(s, 128), smax));
 }
 
-static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs* ws) {
+// rows a training entry point may take: ctx->max_train_batch, or max_batch if that is 0
+static inline int ov_train_cap(const ontovae_ctx_t* c) {
+    return c->max_train_batch > 0 ? std::min(c->max_train_batch, c->max_batch) : c->max_batch;
+}
+
+// train_batch: the buffers only a training pass touches (eps, the column-group-major D panel, the backward's small
+// matrices, the weight-gradient partials: 128 to 512 copies of the packed decoder at inference batch sizes) are sized by it
+static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, int train_batch, void* base, OvWs* ws) {
     const int64_t ldb = ov_ldb(max_batch);
+    const int64_t tldb = ov_ldb(std::min(train_batch, max_batch));
     const int64_t L = d.L, C = d.C, G = d.G;
     int64_t slab = 0;
     for (int b = 64; b <= ldb; b += 64)
@@ -155,19 +163,19 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs
     w.xhat = take(L * ldb);
     w.a = take(L * ldb);
     w.mulv = take(2 * L * ldb);
-    w.epsw = take(L * ldb);
+    w.epsw = take(L * tldb);
     w.act = take(C * ldb);
     w.d = take((C + G) * ldb);
-    w.dblk = take(C * ldb);      // panel rows of D in column-group-major order [ldb / 4][C][4] (backward chain input)
-    w.dmulv = take(2 * L * ldb);
-    w.da = take(L * ldb);
-    w.dh = take(L * ldb);
+    w.dblk = take(C * tldb);     // panel rows of D in column-group-major order [ldb / 4][C][4] (backward chain input)
+    w.dmulv = take(2 * L * tldb);
+    w.da = take(L * tldb);
+    w.dh = take(L * tldb);
     w.bn_mean = take(L);
     w.bn_invstd = take(L);
     w.bn_bwd_local = take(2 * L);
     w.rec_part = take(npart);
     w.kl_part = take(npart);
-    w.wpart = take((ldb / 32) * ((int64_t)d.nnz + C + G));
+    w.wpart = take((tldb / 32) * ((int64_t)d.nnz + C + G));
     w.wgene = take((int64_t)d.nnz - d.nnz_term);
     w.slab_floats = slab;
     w.npart_max = (int)npart;
@@ -177,7 +185,11 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, void* base, OvWs
 
 extern "C" int64_t ontovae_workspace_bytes(const ontovae_dims_t* dims, int32_t max_batch) {
     if (!dims || max_batch < 1) return -1;
-    return ov_carve(*dims, max_batch, nullptr, nullptr);
+    return ov_carve(*dims, max_batch, max_batch, nullptr, nullptr);
+}
+extern "C" int64_t ontovae_workspace_bytes_split(const ontovae_dims_t* dims, int32_t max_batch, int32_t max_train_batch) {
+    if (!dims || max_batch < 1 || max_train_batch < 1) return -1;
+    return ov_carve(*dims, max_batch, max_train_batch, nullptr, nullptr);
 }
 
 // Operand copies of the bf16-MFMA variant (ONTOVAE_FLAG_BF16_GEMM): xb [max_batch, G], xT [G, ldb(max_batch)], wb [L, G],
@@ -2073,7 +2085,7 @@ static inline OvAdam ov_adam_from(const ontovae_adamw_t* o) {
     return a;
 }
 
-static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
+static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt, bool train = false) {
     if (!c) { ontovae_set_error("ctx is NULL"); return ONTOVAE_EINVAL; }
     const ontovae_dims_t& d = c->dims;
     if (d.G < 1 || d.L < 1 || d.C < d.L || d.K < 1 || d.nu < 1 || d.nnz < 0) {
@@ -2090,9 +2102,13 @@ static int ov_check_ctx(const ontovae_ctx_t* c, int B, bool need_opt) {
         ontovae_set_error("batch size %d outside [1, max_batch=%d]", B, c->max_batch);
         return ONTOVAE_EINVAL;
     }
-    if (c->workspace_bytes < ov_carve(d, c->max_batch, nullptr, nullptr)) {
+    if (train && B > ov_train_cap(c)) {
+        ontovae_set_error("ctx: %d rows in a training pass, the workspace is laid out for %d (max_train_batch)", B, ov_train_cap(c));
+        return ONTOVAE_EINVAL;
+    }
+    if (c->workspace_bytes < ov_carve(d, c->max_batch, ov_train_cap(c), nullptr, nullptr)) {
         ontovae_set_error("workspace too small: %lld < %lld bytes", (long long)c->workspace_bytes,
-                          (long long)ov_carve(d, c->max_batch, nullptr, nullptr));
+                          (long long)ov_carve(d, c->max_batch, ov_train_cap(c), nullptr, nullptr));
         return ONTOVAE_EINVAL;
     }
     if (c->flags & ONTOVAE_FLAG_BF16_GEMM) {
@@ -2662,7 +2678,7 @@ static int ov_loss_finalize(OvStep& s, hipStream_t st, int nrec, int nkl, float 
 
 static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int B, void* stream, OvStep* s) {
     s->c = ctx;
-    ov_carve(ctx->dims, ctx->max_batch, ctx->workspace, &s->ws);
+    ov_carve(ctx->dims, ctx->max_batch, ov_train_cap(ctx), ctx->workspace, &s->ws);
     s->B = B;
     s->ldb = ov_ldb(B);
     s->vec = ov_vec(B);
@@ -2706,7 +2722,7 @@ static int ov_transpose_out(OvStep& s, const float* src, int F, float* dst, int6
 // =================================================================================================
 extern "C" int ontovae_forward(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
                                uint64_t rng_offset, int32_t train, float* recon, float* mu, float* log_var, void* stream) {
-    int rc = ov_check_ctx(ctx, B, false);
+    int rc = ov_check_ctx(ctx, B, false, train != 0);
     if (rc) return rc;
     if (!x) { ontovae_set_error("forward: x is NULL"); return ONTOVAE_EINVAL; }
     if (train && B < 2) { ontovae_set_error("forward: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
@@ -3153,7 +3169,7 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply, int l0 = 0, 
 extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
                                   uint64_t rng_offset, float kl_coeff, const ontovae_adamw_t* opt, int32_t apply_update,
                                   float* loss_out, void* stream) {
-    int rc = ov_check_ctx(ctx, B, apply_update != 0);
+    int rc = ov_check_ctx(ctx, B, apply_update != 0, true);
     if (rc) return rc;
     if (!x || !loss_out) { ontovae_set_error("train_step: x or loss_out is NULL"); return ONTOVAE_EINVAL; }
     if (apply_update && !opt) { ontovae_set_error("train_step: opt is NULL"); return ONTOVAE_EINVAL; }
@@ -3181,7 +3197,7 @@ extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, cons
 extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, const float* x, const int32_t* xidx, int32_t B,
                                      int32_t B_global, const float* eps, uint64_t rng_offset, float kl_coeff, float* bn_stats,
                                      float* bn_bwd_stats, float* loss_out, void* stream) {
-    int rc = ov_check_ctx(ctx, B, false);
+    int rc = ov_check_ctx(ctx, B, false, true);
     if (rc) return rc;
     if (!x || !bn_stats || !bn_bwd_stats || !loss_out || !ctx->Gr) { ontovae_set_error("train_step_dp: a required pointer is NULL"); return ONTOVAE_EINVAL; }
     if (B_global < 2 || B_global < B) { ontovae_set_error("train_step_dp: bad global batch %d (local %d)", B_global, B); return ONTOVAE_EINVAL; }
@@ -3219,7 +3235,7 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
 
 extern "C" int ontovae_dw0_rows(const ontovae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, int32_t l0, int32_t l1,
                                 void* stream) {
-    int rc = ov_check_ctx(ctx, B, false);
+    int rc = ov_check_ctx(ctx, B, false, true);
     if (rc) return rc;
     if (!x || !ctx->Gr) { ontovae_set_error("dw0_rows: x or the gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
     if (l0 < 0 || l1 > ctx->dims.L || l0 >= l1) { ontovae_set_error("dw0_rows: rows [%d, %d) outside [0, %d)", l0, l1, ctx->dims.L); return ONTOVAE_EINVAL; }
@@ -3257,7 +3273,7 @@ extern "C" int ontovae_adamw_apply_range(const ontovae_ctx_t* ctx, const ontovae
 
 extern "C" int ontovae_dp_bn_bwd(const ontovae_ctx_t* ctx, int32_t B, int32_t B_global, const float* bn_bwd_stats,
                                  uint64_t rng_offset, float* send, int32_t blm, void* stream) {
-    int rc = ov_check_ctx(ctx, B, false);
+    int rc = ov_check_ctx(ctx, B, false, true);
     if (rc) return rc;
     if (!bn_bwd_stats || !send || !ctx->Gr) { ontovae_set_error("dp_bn_bwd: a required pointer is NULL"); return ONTOVAE_EINVAL; }
     if (blm < B || (blm & 3) || B_global < B) { ontovae_set_error("dp_bn_bwd: blm %d must be a multiple of 4 and >= B = %d", blm, B); return ONTOVAE_EINVAL; }
@@ -3335,7 +3351,7 @@ __global__ __launch_bounds__(256) void ov_dp_dh_kernel(float* __restrict__ gathe
 }
 
 extern "C" int ontovae_dp_pack_dy(const ontovae_ctx_t* ctx, int32_t B, float* send, int32_t blm, void* stream) {
-    int rc = ov_check_ctx(ctx, B, false);
+    int rc = ov_check_ctx(ctx, B, false, true);
     if (rc) return rc;
     if (!send) { ontovae_set_error("dp_pack_dy: send is NULL"); return ONTOVAE_EINVAL; }
     if (blm < B || (blm & 3)) { ontovae_set_error("dp_pack_dy: blm %d must be a multiple of 4 and >= B = %d", blm, B); return ONTOVAE_EINVAL; }
@@ -3364,7 +3380,7 @@ extern "C" int ontovae_dp_dh_global(const ontovae_ctx_t* ctx, int32_t B_global, 
     }
     if (total != B_global) { ontovae_set_error("dp_dh_global: the ranks hold %d rows, B_global = %d", total, B_global); return ONTOVAE_EINVAL; }
     OvWs ws;
-    ov_carve(d, ctx->max_batch, ctx->workspace, &ws);
+    ov_carve(d, ctx->max_batch, ov_train_cap(ctx), ctx->workspace, &ws);
     const ontovae_layout_t& lay = ctx->lay;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     OvProfScope prof(ONTOVAE_PHASE_BN_BWD, st);

@@ -57,6 +57,7 @@ class Engine:
         self.nbt = torch.zeros((), dtype=torch.int64, device=self.device)
         self._ws = None
         self.max_batch = 0
+        self.max_train_batch = 0       # rows a training pass may take: the training-only buffers of the workspace are sized by it
         self._ctx = None
         self._idx = None
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
@@ -173,6 +174,7 @@ class Engine:
                 setattr(self, n, v.to(device))
         self._ws = None
         self.max_batch = 0
+        self.max_train_batch = 0
         self._upload_plan()
         return self
 
@@ -193,19 +195,23 @@ class Engine:
                 "the OntoVAE hot path runs on an MI355X through libontovae_hip.so; there is no CPU path "
                 f"(model is on {self.device})")
 
-    def ctx(self, batch):
-        """The ontovae_ctx_t for a launch with `batch` rows (grows the workspace when needed)."""
+    def ctx(self, batch, train=False):
+        """The ontovae_ctx_t for a launch with `batch` rows (grows the workspace when needed).  train: a training pass, which
+        also uses the training-only buffers (weight-gradient partials: batch / 32 copies of the packed decoder); those are
+        sized by the largest TRAINING batch seen, not by the inference batch."""
         self._require_gpu()
         L = _lib.lib()
-        if batch > self.max_batch:
-            mb = max(int(batch), 128)
-            nbytes = L.ontovae_workspace_bytes(C.byref(self.plan.dims), mb)
+        if batch > self.max_batch or (train and batch > self.max_train_batch):
+            mb = max(int(batch), self.max_batch, 128)
+            mtb = max(int(batch) if train else 0, self.max_train_batch, 128)
+            nbytes = L.ontovae_workspace_bytes_split(C.byref(self.plan.dims), mb, mtb)
             if nbytes <= 0:
                 raise _lib.OntoVAEHipError("workspace sizing failed")
             self._ws = None
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
-            self.max_batch = mb
-            self._bf16_ws = None
+            if mb > self.max_batch:
+                self._bf16_ws = None
+            self.max_batch, self.max_train_batch = mb, mtb
             self._ctx = None
         if (self.flags & _lib.FLAG_BF16_GEMM) and getattr(self, "_bf16_ws", None) is None:
             nb16 = L.ontovae_bf16_workspace_bytes(C.byref(self.plan.dims), self.max_batch)
@@ -238,6 +244,7 @@ class Engine:
             c.workspace = C.c_void_p(aligned)
             c.workspace_bytes = self._ws.numel() - (aligned - base)
             c.max_batch = self.max_batch
+            c.max_train_batch = self.max_train_batch
             c.drop, c.z_drop, c.seed = self.drop, self.z_drop, self.seed
             c.flags = self.flags
             if self.flags & _lib.FLAG_BF16_GEMM:
@@ -301,7 +308,7 @@ class Engine:
         recon = torch.empty(B, p.G, dtype=torch.float32, device=self.device) if want_recon else None
         mu = torch.empty(B, p.L, dtype=torch.float32, device=self.device)
         lv = torch.empty(B, p.L, dtype=torch.float32, device=self.device)
-        ctx = self.ctx(B)
+        ctx = self.ctx(B, train=bool(train))
         _lib.check(_lib.lib().ontovae_forward(C.byref(ctx), _ptr(x), _ptr(xidx), B, _ptr(eps), self.next_offset(),
                                               1 if train else 0, _ptr(recon), _ptr(mu), _ptr(lv), self.stream()), "forward")
         return recon, mu, lv
@@ -329,7 +336,7 @@ class Engine:
             self.ensure_opt_state()
         else:
             self.ensure_grad_buffer()
-        ctx = self.ctx(B)
+        ctx = self.ctx(B, train=True)
         _lib.check(_lib.lib().ontovae_train_step(C.byref(ctx), _ptr(x), _ptr(xidx), B, _ptr(eps), self.next_offset(),
                                                  float(kl_coeff), C.byref(adam) if adam is not None else None,
                                                  1 if apply_update else 0, _ptr(loss_out), self.stream()), "train_step")
@@ -339,7 +346,7 @@ class Engine:
         x, xidx, B = self._x(x, xidx)
         eps = self._eps(eps, B)
         self.ensure_grad_buffer()
-        ctx = self.ctx(B)
+        ctx = self.ctx(B, train=True)
         _lib.check(_lib.lib().ontovae_train_step_dp(C.byref(ctx), phase, _ptr(x), _ptr(xidx), B, int(B_global), _ptr(eps),
                                                     offset, float(kl_coeff), _ptr(bn_stats), _ptr(bn_bwd_stats),
                                                     _ptr(loss_out), self.stream()), f"train_step_dp phase {phase}")
@@ -362,7 +369,7 @@ class Engine:
     @_on_device
     def dp_bn_bwd(self, B, B_global, bn_bwd_stats, offset, send, blm):
         self.ensure_grad_buffer()
-        ctx = self.ctx(B)
+        ctx = self.ctx(B, train=True)
         _lib.check(_lib.lib().ontovae_dp_bn_bwd(C.byref(ctx), int(B), int(B_global), _ptr(bn_bwd_stats), offset, _ptr(send),
                                                 int(blm), self.stream()), "dp_bn_bwd")
 
@@ -370,13 +377,13 @@ class Engine:
     def dw0_rows(self, x, xidx, l0, l1):
         """Rows [l0, l1) of dW0 = dh x of this rank's rows into Gr (after train_step_dp phase 3)."""
         x, xidx, B = self._x(x, xidx)
-        ctx = self.ctx(B)
+        ctx = self.ctx(B, train=True)
         _lib.check(_lib.lib().ontovae_dw0_rows(C.byref(ctx), _ptr(x), _ptr(xidx), B, int(l0), int(l1), self.stream()), "dw0_rows")
 
     @_on_device
     def dp_pack_dy(self, B, send, blm):
         """After DP phase 1: this rank's block [dy | b0 slot | xhat | local sums] for the single all-gather."""
-        ctx = self.ctx(B)
+        ctx = self.ctx(B, train=True)
         _lib.check(_lib.lib().ontovae_dp_pack_dy(C.byref(ctx), int(B), _ptr(send), int(blm), self.stream()), "dp_pack_dy")
 
     @_on_device

@@ -487,6 +487,41 @@ def test_small_gene_count_heads_output_fits_workspace(B):
         assert np.abs(v.cpu().numpy() - g[k]).max() <= 2e-5 * np.abs(g[k]).max(), k
 
 
+def test_workspace_sizes_training_buffers_by_the_training_batch():
+    """An inference pass at 4096 rows before training: the training-only buffers (weight-gradient partials, one copy of the
+    packed decoder per 32 rows) stay sized for the training batch, the step lands where the one of a model that never served
+    a large batch lands, and the library refuses a training pass beyond ctx.max_train_batch."""
+    import ctypes as C
+    from onto_vae_amd import _lib
+    from onto_vae_amd.vae_model import FusedAdamW
+    masks, sd = medium()
+    rng = np.random.RandomState(5)
+    X = torch.as_tensor(np.log1p(rng.poisson(0.5, size=(4096, 1000))).astype(np.float32)).cuda()
+    eps = torch.as_tensor(rng.standard_normal((100, 60)).astype(np.float32))
+    a, _ = make_model(masks, 3, sd)
+    b, _ = make_model(masks, 3, sd)
+    ea, eb = a._engine, b._engine
+    out = torch.empty(4096, ea.plan.T, device="cuda")
+    ea.pass_data(X, None, None, None, act_out=out)
+    assert (ea.max_batch, ea.max_train_batch) == (4096, 128)
+    L = _lib.lib()
+    assert ea._ws.numel() - 256 == L.ontovae_workspace_bytes_split(C.byref(ea.plan.dims), 4096, 128)
+    assert ea._ws.numel() - 256 < 0.7 * L.ontovae_workspace_bytes(C.byref(ea.plan.dims), 4096)
+    la, lb = torch.zeros(3, device="cuda"), torch.zeros(3, device="cuda")
+    ea.train_step(X[:100], None, eps, 1e-4, FusedAdamW(a, lr=1e-3).next_hyper(), la)
+    eb.train_step(X[:100], None, eps, 1e-4, FusedAdamW(b, lr=1e-3).next_hyper(), lb)
+    # not bitwise: a larger workspace admits more split-K slabs in the small GEMMs (another summation order)
+    assert torch.allclose(la, lb, rtol=1e-6) and float((ea.P - eb.P).abs().max()) <= 2.1e-3 and float(((ea.P - eb.P).abs() > 1e-6).float().mean()) < 0.01
+    assert (ea.max_batch, ea.max_train_batch) == (4096, 128)
+    ctx = ea.ctx(128, train=True)
+    xs = X[:200].contiguous()
+    rc = L.ontovae_train_step(C.byref(ctx), C.c_void_p(xs.data_ptr()), None, 200, None, 7, 1e-4,
+                              C.byref(FusedAdamW(a, lr=1e-3).next_hyper()), 1, C.c_void_p(la.data_ptr()), ea.stream())
+    assert rc == -1 and b"max_train_batch" in L.ontovae_last_error()
+    ea.train_step(X[:200], None, None, 1e-4, FusedAdamW(a, lr=1e-3).next_hyper(), la)        # the engine grows the buffers itself
+    assert ea.max_train_batch == 200 and bool(torch.isfinite(la).all())
+
+
 def test_row_gather_equals_plain_batch():
     """(dataset, row indices) addressing gives the same step as a gathered batch."""
     from onto_vae_amd.vae_model import FusedAdamW
