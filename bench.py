@@ -168,7 +168,7 @@ def _timed(fn, steps, world, dev):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -407,12 +407,20 @@ def main():
             raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the OntoVAE hot path has no CPU fallback")
+    # ONTOVAE_BENCH_SHARED_GPU=1: rehearsal of the multi-rank code path on a box with ONE GPU (all ranks on cuda:0, gloo with
+    # host-staged collectives).  Its numbers mean nothing; the line says so.
+    rehearsal = world > 1 and os.environ.get("ONTOVAE_BENCH_SHARED_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     model, masks = build_model(dev)
     e = model._engine
@@ -497,6 +505,8 @@ def main():
                "final_loss": final_loss}
         if single_same is not None:
             out["single_gpu_same_global_batch"] = single_same
+        if rehearsal:
+            out["rehearsal"] = "all ranks share cuda:0, gloo with host-staged collectives: code-path check only, not a measurement"
         if world == 1 and not a.no_extras and B == 128 and a.global_batch is None and a.dtype == "f32" and a.ontology == "gobp":
             # the other headline workloads, measured after the timed region so that the driver's run covers them too
             xa = argparse.Namespace(**vars(a))

@@ -447,3 +447,24 @@ def test_bf16_variant_vs_oracle(which):
     w_hip, w_ref, w0 = m3._engine.view("W0").cpu().numpy(), o3.p["encoder.encoder.0.0.weight"], np.asarray(sd["encoder.encoder.0.0.weight"])
     du_h, du_r = (w_hip - w0).ravel(), (w_ref - w0).ravel()
     assert float(du_h @ du_r / (np.linalg.norm(du_h) * np.linalg.norm(du_r))) >= 0.9      # Adam's sign-like steps agree on most weights
+
+
+def test_bench_multi_rank_code_path_rehearsal():
+    """The command line the driver uses for N > 1 (torch.distributed.run, one rank per GPU, configs[2]) with both ranks on this
+    box's one GPU and gloo in place of RCCL (ONTOVAE_BENCH_SHARED_GPU=1): the line must carry configs[2]'s workload, strong
+    scaling, the one-GPU time of the same global batch, and a finite loss.  Its throughput means nothing."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ONTOVAE_BENCH_SHARED_GPU="1")
+    port = str(29700 + (os.getpid() % 200))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--rows", "8192"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=160, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 8192 and d["config"]["batch_per_gpu"] == 4096
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["parallelism"] == "dp2"
+    assert d["single_gpu_same_global_batch"]["n_gpus"] == 1 and d["single_gpu_same_global_batch"]["value"] > 0
+    assert np.isfinite(d["final_loss"]) and d["value"] > 0 and "rehearsal" in d
