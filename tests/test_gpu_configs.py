@@ -181,6 +181,58 @@ def test_gobp_syn_inference_vs_oracle(batch):
     assert act_close(a_out.cpu().numpy(), want_act) and act_close(r_out.cpu().numpy(), recon)
 
 
+def test_gobp_syn_full_size_properties():
+    """configs[3] at a size no oracle pass covers (65536 rows of GOBP-syn in batches of 16384): properties that do not depend on
+    the size.  (1) The decoder is linear (modules.py:303-313 has no activation): dec(z1 + z2) - dec(0) = (dec(z1) - dec(0)) +
+    (dec(z2) - dec(0)).  (2) Rows are independent in eval mode: permuting the dataset permutes the activities, and the batch
+    size does not matter.  (3) Perturbing a gene that no row expresses to 0 changes nothing; the rank-1 screen pass of an empty
+    perturbation list equals the plain pass."""
+    masks, sd, X = gobp()
+    N = 65536
+    rng = np.random.RandomState(65536)
+    rows = rng.randint(0, X.shape[0], size=N)
+    Xd = torch.as_tensor(X[rows] * rng.uniform(0.5, 1.5, size=(N, 1)).astype(np.float32)).cuda()
+    model, onto = make_model(masks, 3, sd, X=np.zeros((4, 20000), np.float32))
+    model.eval()
+    e = model._engine
+    # (1) linearity of the decoder, activities and reconstruction
+    n = 16384
+    z1 = torch.as_tensor(rng.standard_normal((n, 360)).astype(np.float32)).cuda()
+    z2 = torch.as_tensor(rng.standard_normal((n, 360)).astype(np.float32)).cuda()
+
+    def dec(z):
+        a, r = torch.empty(n, 3000, device="cuda"), torch.empty(n, 20000, device="cuda")
+        e.decoder_forward(z, act_out=a, rec_out=r)
+        return a, r
+    a0, r0 = dec(torch.zeros_like(z1))
+    a1, r1 = dec(z1)
+    a2, r2 = dec(z2)
+    a12, r12 = dec(z1 + z2)
+    for lhs, rhs in (((a12 - a0), (a1 - a0) + (a2 - a0)), ((r12 - r0), (r1 - r0) + (r2 - r0))):
+        scale = float(rhs.abs().max())
+        assert float((lhs - rhs).abs().max()) <= 2e-5 * scale
+    del a0, r0, a1, r1, a2, r2, a12, r12
+    # (2) row independence: permutation equivariance and batch-size invariance, with eps = 0 (the draws are keyed by position)
+    zero = lambda B: torch.zeros(B, 360)
+    model.eps_source = zero
+    model.inference_batch = 16384
+    act = torch.as_tensor(model._pass_data(Xd, 'act'))
+    assert act.shape == (N, 3000) and bool(torch.isfinite(act).all())
+    perm = torch.as_tensor(rng.permutation(N))
+    act_p = torch.as_tensor(model._pass_data(Xd[perm.cuda()].contiguous(), 'act'))
+    assert float((act_p - act[perm]).abs().max()) <= 2e-5 * float(act.abs().max())
+    model.inference_batch = 4096
+    act_s = torch.as_tensor(model._pass_data(Xd[:8192], 'act'))
+    assert float((act_s - act[:8192]).abs().max()) <= 2e-5 * float(act.abs().max())
+    # (3) the rank-1 screen pass with an empty perturbation list is the plain pass
+    hpre = torch.empty(360, 4096, device="cuda")
+    xb = Xd[:4096]
+    e.encode_pre(xb, None, hpre, 0)
+    out = torch.empty(4096, 3000, device="cuda")
+    e.pass_data_perturbed(xb, None, hpre, 0, np.zeros(0, np.int32), np.zeros(0, np.float32), zero(4096), zero(4096), act_out=out)
+    assert float((out.cpu() - act[:4096]).abs().max()) <= 2e-5 * float(act.abs().max())
+
+
 # ---------------------------------------------------------------------------------------------- configs[0]
 PWO_COUNTS = [76, 3, 12, 131, 169, 160, 101, 5]      # SURVEY.md 0.3: terms per depth of the trimmed Pathway Ontology
 
