@@ -16,7 +16,12 @@ def main():
     faulthandler.dump_traceback_later(100, exit=True)      # a hung collective ends the worker with a traceback, not the box's limit
     rank, world, port, path, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("ONTOVAE_DP_WORKER_BACKEND", "gloo")      # "nccl" (RCCL) only with one rank per GPU: world size 1 here
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from onto_vae_amd.synthetic import StubOntobj
     from onto_vae_amd.vae_model import OntoVAE, FusedAdamW
     from onto_vae_amd.parallel import dp_train_step

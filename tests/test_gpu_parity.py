@@ -710,6 +710,45 @@ def test_dp_two_processes_one_gpu(tmp_path, use_idx, allreduce):
     assert (diff > 1e-6 + 1e-4 * np.abs(want[mask])).mean() <= 0.01 and diff.max() <= 2 * steps * lr
 
 
+@pytest.mark.parametrize("allreduce", [0, 1])
+def test_dp_rccl_stream_ordered_path_world_size_one(tmp_path, allreduce):
+    """The collectives of dp_train_step as the multi-GPU run issues them: backend nccl (RCCL), asynchronous all-reduces left
+    outstanding under the following launches and waited for later.  One GPU allows one RCCL rank, so the world is 1 (the
+    collectives are self-loops, the stream ordering, handles and buffer reuse are the real ones); both exchange forms; three
+    steps must land where the fused single-GPU steps land."""
+    import subprocess
+    import sys
+    from onto_vae_amd.vae_model import FusedAdamW
+    masks, sd = medium()
+    rng = np.random.RandomState(9)
+    B, steps, lr = 100, 3, 1e-3
+    X = np.log1p(rng.poisson(0.5, size=(400, 1000))).astype(np.float32)
+    idx = rng.permutation(400)[:B * steps].astype(np.int32)
+    eps = rng.standard_normal((steps, B, 60)).astype(np.float32)
+    path = str(tmp_path / "dp_case.npz")
+    np.savez(path, nmask=len(masks), nu=3, X=X, idx=idx, eps=eps, B=B, lr=lr, use_idx=1,
+             **{f"mask{i}": m for i, m in enumerate(masks)}, **{"sd:" + k: np.asarray(v) for k, v in sd.items()})
+    ref, _ = make_model(masks, 3, sd)
+    ropt = FusedAdamW(ref, lr=lr)
+    rl = torch.zeros(steps, 3, device="cuda")
+    Xd = torch.as_tensor(X).cuda()
+    for s in range(steps):
+        ref._engine.train_step(Xd, torch.as_tensor(idx[s * B:(s + 1) * B]).cuda(), torch.as_tensor(eps[s]), 1e-4,
+                               ropt.next_hyper(), rl[s])
+    env = dict(os.environ, ONTOVAE_DP_ALLREDUCE=str(allreduce), ONTOVAE_DP_WORKER_BACKEND="nccl")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker.py")
+    p = subprocess.Popen([sys.executable, worker, "0", "1", str(29300 + (os.getpid() % 300)), path, str(steps)], env=env)
+    assert p.wait(timeout=160) == 0
+    got = np.load(path + ".rank0.npz")
+    np.testing.assert_allclose(got["losses"], rl.cpu().numpy(), rtol=2e-5)
+    e = ref._engine
+    want = e.P.cpu().numpy()
+    mask = np.ones(want.shape, bool)
+    mask[int(e.plan.layout.b0):int(e.plan.layout.b0) + e.plan.L] = False
+    diff = np.abs(got["P"] - want)[mask]
+    assert (diff > 1e-6 + 1e-4 * np.abs(want[mask])).mean() <= 0.01 and diff.max() <= 2 * steps * lr
+
+
 def test_train_model_resume_equals_uninterrupted(tmp_path, capsys):
     """train_model(resume=...) (the reference cannot resume): 2 epochs + resume to 4 equals 4
     epochs in one go, bit for bit, with dropout on (parameters, optimizer state, batch order, Philox offsets restored)."""
