@@ -390,7 +390,7 @@ static int ov_vae_block_bwd(OvVaeStep& s, const OvVaeLayer& l, const float* ga, 
                          Gr ? Gr + l.gamma : nullptr, Gr ? Gr + l.beta : nullptr, Gr ? Gr + l.b : nullptr, s.ws.dh, s.ws.bwd_local,
                          (float*)nullptr, l.out, s.B, s.B, s.ldb, 1, s.apply, s.adam, c->drop, c->seed, ov_vae_layer_off(s.rng_off, k), daS,
                          (int64_t)l.out * s.ldb, nullptr, 0};
-    hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((l.out + 3) / 4), dim3(256), 0, s.st, bn);
+    hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3(l.out), dim3(256), 0, s.st, bn);
     OV_LAUNCH_CHECK();
     int rc;
     if (dprev && (rc = ov_vae_da(s, c->P + l.W, l.out, l.in, s.ws.dh, dprev, S_out, keep_slabs))) return rc;    // before W is updated
@@ -432,7 +432,7 @@ extern "C" int ontovae_vae_train_step(const ontovae_vae_ctx_t* ctx, const float*
     {
         OvLatentArgs la{s.ws.dz, s.ws.mulv, s.ws.epsw, s.ws.dmulv, n.Z, s.B, s.ldb, kl_coeff, ctx->z_drop, ctx->seed, rng_offset,
                         ctx->P + n.bh, ctx->M ? ctx->M + n.bh : nullptr, ctx->V ? ctx->V + n.bh : nullptr, ctx->Gr ? ctx->Gr + n.bh : nullptr,
-                        s.apply, s.adam, OvLossArgs{s.ws.rec_part, nrec, s.ws.kl_part, nkl, kl_coeff, loss_out}, (n.Z + 3) / 4 + 1};
+                        s.apply, s.adam, OvLossArgs{s.ws.rec_part, nrec, s.ws.kl_part, nkl, kl_coeff, loss_out}, n.Z + 1};
         OvWgradArgs none{};
         hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(la.nblocks), dim3(256), 0, s.st, la, none, 0);
         OV_LAUNCH_CHECK();

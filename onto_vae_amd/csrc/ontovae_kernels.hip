@@ -394,8 +394,11 @@ struct OvBnBwdArgs {
     int daS; int64_t dastride;
     float* send; int blm;          // mode 4: also [L][blm] dh + [L] local b0 gradient for the all-gather
 };
-// block: this workgroup's number inside the BatchNorm part, 4 features per workgroup
+// block: this workgroup's number inside the BatchNorm part = the feature.  The four waves take every fourth chunk of 64
+// columns (a wave per feature walked 8192 columns in 128 dependent trips: 249 us at that batch); their sums are combined
+// through LDS in a fixed order.
 __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int block) {
+    __shared__ float bn_red[3][4];
     const float* __restrict__ da = q.da; const float* __restrict__ a = q.a; const float* __restrict__ xhat = q.xhat;
     const float* __restrict__ invstd = q.invstd;
     float* __restrict__ P_gamma = q.P_gamma; float* __restrict__ P_beta = q.P_beta; float* __restrict__ P_b0 = q.P_b0;
@@ -406,13 +409,14 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
     const int L = q.L, B = q.B, Bglobal = q.Bglobal, ldb = q.ldb, mode = q.mode, apply_update = q.apply_update;
     const OvAdam adam = q.adam; const float drop = q.drop; const uint64_t seed = q.seed, rng_off = q.rng_off;
     const int daS = q.daS; const int64_t dastride = q.dastride;
-    const int l = block * 4 + ov_wave_id();
-    if (l >= L) return;
+    const int l = block;
+    if (l >= L) return;                            // workgroup-uniform
     const int lane = ov_lane();
+    const int wave = ov_wave_id();
     const int64_t ro = (int64_t)l * ldb;
     float sdy = 0.f, sdyx = 0.f;
     if (mode < 3) {
-        for (int b = lane; b < ldb; b += 64) {
+        for (int b = wave * 64 + lane; b < ldb; b += 256) {
             float dy = 0.f;
             if (b < B) {
                 if (a[ro + b] > 0.f)
@@ -425,8 +429,12 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
         }
         sdy = ov_wave_sum(sdy);
         sdyx = ov_wave_sum(sdyx);
+        if (lane == 0) { bn_red[0][wave] = sdy; bn_red[1][wave] = sdyx; }
+        __syncthreads();
+        sdy = (bn_red[0][0] + bn_red[0][1]) + (bn_red[0][2] + bn_red[0][3]);
+        sdyx = (bn_red[1][0] + bn_red[1][1]) + (bn_red[1][2] + bn_red[1][3]);
         if (mode == 2) {
-            if (lane == 0) {
+            if (threadIdx.x == 0) {
                 bwd_local[l] = sdy; bwd_local[L + l] = sdyx;
                 bwd_stats[l] = sdy; bwd_stats[L + l] = sdyx;
             }
@@ -444,7 +452,7 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
     const float nb = (float)Bglobal;
     const float scale = g * is / nb;
     float sdh = 0.f;
-    for (int b = lane; b < ldb; b += 64) {
+    for (int b = wave * 64 + lane; b < ldb; b += 256) {          // the columns this thread wrote above
         float v = 0.f;
         if (b < B) {
             v = scale * (nb * dh[ro + b] - gdy - xhat[ro + b] * gdyx);
@@ -454,8 +462,11 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
         if (mode == 4 && b < q.blm) q.send[(int64_t)l * q.blm + b] = v;
     }
     sdh = ov_wave_sum(sdh);
-    if (mode == 4 && lane == 0) q.send[(int64_t)L * q.blm + l] = sdh;
-    if (lane == 0) {
+    if (lane == 0) bn_red[2][wave] = sdh;
+    __syncthreads();
+    sdh = (bn_red[2][0] + bn_red[2][1]) + (bn_red[2][2] + bn_red[2][3]);
+    if (mode == 4 && threadIdx.x == 0) q.send[(int64_t)L * q.blm + l] = sdh;
+    if (threadIdx.x == 0) {
         if (apply_update) {
             float w, m, v;
             w = P_gamma[l]; m = M_gamma[l]; v = V_gamma[l]; ov_adamw(w, m, v, sdyx, adam, false); P_gamma[l] = w; M_gamma[l] = m; V_gamma[l] = v;
@@ -557,7 +568,7 @@ struct OvLatentArgs {
     int L, B, ldb; float kc, z_drop; uint64_t seed, rng_off;
     float* bh; float* mbh; float* vbh; float* gbh; int apply_update; OvAdam adam;
     OvLossArgs la;
-    int nblocks;          // (L + 3) / 4 feature blocks + 1 loss block
+    int nblocks;          // L feature blocks + 1 loss block
 };
 // block: this workgroup's number inside the latent part, in [0, nblocks)
 __device__ __forceinline__ void ov_latent_bwd_body(const OvLatentArgs& a, const int block) {
@@ -581,12 +592,15 @@ __device__ __forceinline__ void ov_latent_bwd_body(const OvLatentArgs& a, const 
         }
         return;
     }
+    // one workgroup per latent feature, the four waves take every fourth chunk of 64 columns (see ov_bn_bwd_body)
+    __shared__ float lat_red[2][4];
     const int L = a.L, B = a.B, ldb = a.ldb;
-    const int l = block * 4 + ov_wave_id();
-    if (l >= L) return;
+    const int l = block;
+    const int wave = ov_wave_id();
+    if (l >= L) return;                            // workgroup-uniform
     const int64_t n = (int64_t)L * ldb;
     float smu = 0.f, slv = 0.f;
-    for (int b = lane; b < ldb; b += 64) {
+    for (int b = wave * 64 + lane; b < ldb; b += 256) {
         const int64_t idx = (int64_t)l * ldb + b;
         float dmu = 0.f, dlv = 0.f;
         if (b < B) {
@@ -605,9 +619,13 @@ __device__ __forceinline__ void ov_latent_bwd_body(const OvLatentArgs& a, const 
     }
     smu = ov_wave_sum(smu);
     slv = ov_wave_sum(slv);
-    if (lane < 2) {                     // lane 0: bias of mu[l]; lane 1: bias of log_var[l]
-        const int r = lane == 0 ? l : L + l;
-        const float g = lane == 0 ? smu : slv;
+    if (lane == 0) { lat_red[0][wave] = smu; lat_red[1][wave] = slv; }
+    __syncthreads();
+    smu = (lat_red[0][0] + lat_red[0][1]) + (lat_red[0][2] + lat_red[0][3]);
+    slv = (lat_red[1][0] + lat_red[1][1]) + (lat_red[1][2] + lat_red[1][3]);
+    if (threadIdx.x < 2) {              // thread 0: bias of mu[l]; thread 1: bias of log_var[l]
+        const int r = threadIdx.x == 0 ? l : L + l;
+        const float g = threadIdx.x == 0 ? smu : slv;
         if (a.apply_update) {
             float ww = a.bh[r], mm = a.mbh[r], vv = a.vbh[r];
             ov_adamw(ww, mm, vv, g, a.adam, false);
@@ -1721,8 +1739,17 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
     const bool terms = a.sel != 1, genes = a.sel != 2;
     const int64_t kb = terms ? 0 : a.nnz_term, ke = genes ? a.nnz : a.nnz_term;
     for (int64_t k = kb + first; k < ke; k += stride) {
+        // the column blocks' partials in a fixed order; eight loads in flight (at 256 blocks this pass reads 0.5 GB)
         float g = 0.f;
-        for (int cb = 0; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
+        int cb = 0;
+        for (; cb + 8 <= a.ncb; cb += 8) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = a.part[(int64_t)(cb + j) * a.nnz + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g += t[j];
+        }
+        for (; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
         update(k, g);
     }
     const int rb = terms ? 0 : a.n_term_rows, re = genes ? a.nrows : a.n_term_rows;
@@ -3041,7 +3068,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         OvLatentArgs la{s.ws.d + (int64_t)(d.C - d.L) * s.ldb, s.ws.mulv, s.ws.epsw, s.ws.dmulv, d.L, s.B, s.ldb, kc, c->z_drop,
                         c->seed, rng_off, c->P + lay.bh, c->M ? c->M + lay.bh : nullptr, c->V ? c->V + lay.bh : nullptr,
                         c->Gr ? c->Gr + lay.bh : nullptr, apply, adam,
-                        OvLossArgs{s.ws.rec_part, ov_nrec(s), s.ws.kl_part, nkl, kc, loss_out}, (d.L + 3) / 4 + 1};
+                        OvLossArgs{s.ws.rec_part, ov_nrec(s), s.ws.kl_part, nkl, kc, loss_out}, d.L + 1};
         OvProfScope prof(ONTOVAE_PHASE_LATENT_BWD, s.st);
         hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(la.nblocks + (riders2 ? wteams : 0)), dim3(256), 0, s.st, la, wt,
                            riders2 ? wteams : 0);
@@ -3084,7 +3111,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                          c->V ? c->V + lay.b0 : nullptr, Gr ? Gr + lay.gamma : nullptr, Gr ? Gr + lay.beta : nullptr,
                          Gr ? Gr + lay.b0 : nullptr, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, s.B, Bglobal, s.ldb, bn_mode,
                          apply, adam, c->drop, c->seed, rng_off, da_S, (int64_t)d.L * s.ldb, nullptr, 0};
-    const int bn_blocks = (d.L + 3) / 4;
+    const int bn_blocks = d.L;
     if (!s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS)) {
         OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
         const int gx = (gw.N + 31) / 32, gy = (gw.M + 31) / 32;
@@ -3224,7 +3251,7 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->Gr + lay.gamma, ctx->Gr + lay.beta,
                              ctx->Gr + lay.b0, s.ws.dh, s.ws.bn_bwd_local, bn_bwd_stats, d.L, B, B_global, s.ldb, 3, 0, adam,
                              ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0, nullptr, 0};
-        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, bn);
+        hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3(d.L), dim3(256), 0, s.st, bn);
         OV_LAUNCH_CHECK();
         if (phase == 3) return ONTOVAE_OK;          // dW0 follows in row panels (ontovae_dw0_rows)
         return ov_dw0(s, nullptr, 0);
@@ -3288,7 +3315,7 @@ extern "C" int ontovae_dp_bn_bwd(const ontovae_ctx_t* ctx, int32_t B, int32_t B_
                          ctx->Gr + lay.b0, s.ws.dh, s.ws.bn_bwd_local, const_cast<float*>(bn_bwd_stats), d.L, B, B_global, s.ldb, 4, 0,
                          adam, ctx->drop, ctx->seed, rng_offset, 1, (int64_t)0, send, blm};
     OvProfScope prof(ONTOVAE_PHASE_BN_BWD, s.st);
-    hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3((d.L + 3) / 4), dim3(256), 0, s.st, bn);
+    hipLaunchKernelGGL(ov_bn_bwd_kernel, dim3(d.L), dim3(256), 0, s.st, bn);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }

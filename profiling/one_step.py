@@ -1,5 +1,5 @@
 """A few training steps of the bench model and nothing else: the program rocprofv3's --pmc passes wrap (one counter group
-per run; see profiles/*/README.md).  usage: python3 profiling/one_step.py [steps] [batch] [mode: train|infer]"""
+per run; see profiles/*/README.md).  usage: python3 profiling/one_step.py [steps] [batch] [mode: train|infer] [ctx flags, e.g. 16 = no riders]"""
 import os
 import sys
 
@@ -15,6 +15,9 @@ mode = sys.argv[3] if len(sys.argv) > 3 else "train"
 dev = torch.device("cuda", 0)
 model, masks = bench.build_model(dev)
 e = model._engine
+if len(sys.argv) > 4:
+    e.flags = int(sys.argv[4])
+    e.invalidate()
 X = bench.synth_X(max(4096, B), 20000, dev)
 if mode == "train":
     opt = FusedAdamW(model, lr=1e-4)
