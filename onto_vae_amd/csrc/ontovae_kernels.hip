@@ -577,8 +577,23 @@ __device__ __forceinline__ void ov_latent_bwd_body(const OvLatentArgs& a, const 
         __shared__ double red[2][4];
         const OvLossArgs& la = a.la;
         double r = 0.0, k = 0.0;
-        for (int i = threadIdx.x; i < la.nrec; i += 256) r += (double)la.rec_part[i];
-        for (int i = threadIdx.x; i < la.nkl; i += 256) k += (double)la.kl_part[i];
+        // one workgroup sums every partial of the step (160 k of them at 8192 rows): eight loads in flight per thread, or the
+        // loop is one memory round trip per element (268 us at that batch)
+        auto total = [&](const float* __restrict__ p, int n) {
+            double acc = 0.0;
+            int i = threadIdx.x;
+            for (; i + 7 * 256 < n; i += 8 * 256) {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = p[i + j * 256];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += (double)t[j];
+            }
+            for (; i < n; i += 256) acc += (double)p[i];
+            return acc;
+        };
+        r = total(la.rec_part, la.nrec);
+        k = total(la.kl_part, la.nkl);
         r = ov_wave_sum_d(r);
         k = ov_wave_sum_d(k);
         if (lane == 0) { red[0][threadIdx.x >> 6] = r; red[1][threadIdx.x >> 6] = k; }
@@ -1922,8 +1937,21 @@ __global__ __launch_bounds__(1024) void ov_loss_finalize_kernel(const float* __r
                                                                float* __restrict__ out) {
     __shared__ double red[2][16];
     double r = 0.0, k = 0.0;
-    for (int i = threadIdx.x; i < nrec; i += 1024) r += (double)rec_part[i];
-    for (int i = threadIdx.x; i < nkl; i += 1024) k += (double)kl_part[i];
+    auto total = [&](const float* __restrict__ p, int n) {          // eight loads in flight per thread
+        double acc = 0.0;
+        int i = threadIdx.x;
+        for (; i + 7 * 1024 < n; i += 8 * 1024) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[i + j * 1024];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (double)t[j];
+        }
+        for (; i < n; i += 1024) acc += (double)p[i];
+        return acc;
+    };
+    r = total(rec_part, nrec);
+    k = total(kl_part, nkl);
     r = ov_wave_sum_d(r);
     k = ov_wave_sum_d(k);
     if (ov_lane() == 0) {
