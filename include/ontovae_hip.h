@@ -140,6 +140,27 @@ int ontovae_plan_sell_sizes(const ontovae_plan_t* plan, int32_t dir, int32_t* n_
 int ontovae_plan_sell_export(const ontovae_plan_t* plan, int32_t dir, int32_t* level_first, int32_t* level_count,
                              int32_t* node, int32_t* info, int32_t* chunk0, int32_t* idx, int32_t* k);
 
+/* SELL-64 form of the GENE layer for the LDS-panel forward kernel of the training pass (a workgroup holds the 4 batch columns
+ * of all C panel rows in LDS and walks the genes' lists against it): one gene per lane, genes sorted by list length inside
+ * windows of 512 consecutive genes and cut into slices of 64 lanes.  The lists are stored in quads of 4 entries: quad q of
+ * slice s, lane l is element (quad0[s] + q) * 64 + l of `col` (4 x uint16 panel rows), `k` (4 packed positions, -1 =
+ * padding: weight 0, row 0) and `w`.  n_slices == 0 (not provided, or a panel index that does not fit 16 bits): the
+ * 32-column-block kernel runs instead.
+ * The library keeps a weight copy in this order (`w`, refreshed from P at the start of every training pass).
+ * Replaces the per-row walk of the masked matmul of onto_vae/modules.py:308-312 for the last decoder layer. */
+typedef struct ontovae_gsell {
+    int32_t n_slices;
+    int32_t n_quads;
+    const int32_t* gene;          /* device [n_slices * 64] gene of each lane, -1 = unused lane */
+    const int32_t* quad0;         /* device [n_slices + 1] */
+    const uint16_t* col;          /* device [n_quads * 256] */
+    const int32_t* k;             /* device [n_quads * 256] */
+    float* w;                     /* device scratch [n_quads * 256] */
+} ontovae_gsell_t;
+
+int ontovae_plan_gsell_sizes(const ontovae_plan_t* plan, int32_t* n_slices, int32_t* n_quads);
+int ontovae_plan_gsell_export(const ontovae_plan_t* plan, int32_t* gene, int32_t* quad0, uint16_t* col, int32_t* k);
+
 typedef struct ontovae_layout {
     int64_t W0;      /* [L, G]   encoder.encoder.0.0.weight                                   */
     int64_t b0;      /* [L]      encoder.encoder.0.0.bias                                     */
@@ -192,10 +213,12 @@ typedef struct ontovae_ctx {
      * device memory, 256-B aligned; NULL / 0 otherwise */
     void* bf16_ws;
     int64_t bf16_ws_bytes;
+    ontovae_gsell_t gsell;     /* n_slices == 0: not provided */
 } ontovae_ctx_t;
 
 #define ONTOVAE_FLAG_LEVEL_LAUNCHES 1u  /* one launch per decoder level instead of the LDS-fused chain */
 #define ONTOVAE_FLAG_ROW_GENE_LAYER 2u  /* row-per-wave gene layer instead of the LDS-tiled one */
+#define ONTOVAE_FLAG_CB_GENE_FWD 128u   /* training forward of the gene layer on 32-column blocks (gathers from L2) instead of the LDS-panel kernel */
 #define ONTOVAE_FLAG_WIDE_GENE_TILES 8u /* gene layer: waves that span 64-256 batch columns instead of XCD-pinned 32-column blocks */
 /* Any other bit is refused with ONTOVAE_EINVAL (measurement switches exist only in -DOV_MEASUREMENT_SWITCHES builds). */
 /* BASELINE.json configs[4], "bf16 MFMA variant": the two large dense products of a pass -- x W0^T (onto_vae/modules.py:46) and its

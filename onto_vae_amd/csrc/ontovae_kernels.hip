@@ -25,7 +25,7 @@
 
 #define OV_LAUNCH_CHECK() OV_HIP_CHECK(hipGetLastError())
 
-#define OV_KNOWN_FLAGS (ONTOVAE_FLAG_LEVEL_LAUNCHES | ONTOVAE_FLAG_ROW_GENE_LAYER | ONTOVAE_FLAG_SIDE_STREAM | ONTOVAE_FLAG_WIDE_GENE_TILES | ONTOVAE_FLAG_NO_RIDERS | ONTOVAE_FLAG_BF16_GEMM)
+#define OV_KNOWN_FLAGS (ONTOVAE_FLAG_LEVEL_LAUNCHES | ONTOVAE_FLAG_ROW_GENE_LAYER | ONTOVAE_FLAG_SIDE_STREAM | ONTOVAE_FLAG_WIDE_GENE_TILES | ONTOVAE_FLAG_NO_RIDERS | ONTOVAE_FLAG_BF16_GEMM | ONTOVAE_FLAG_CB_GENE_FWD)
 
 // batch columns per wave pass (64 lanes x VEC) and the padded row length, a multiple of it
 // -------------------------------------------------------------------------------------------------
@@ -118,6 +118,7 @@ struct OvWs {
     float *rec_part, *kl_part;
     float *wpart;              // [ldb / 32][nnz + C + G] weight-gradient partials of the 32-column blocks
     float *wgene;              // [nnz - nnz_term] gene-layer weights in CSR order, refreshed from P at the start of every pass
+    float *gb4;                // [ldb / 4][lanes of the gene layer's SELL form] gene bias gradient partials of ov_gene_lds_kernel
     int64_t slab_floats;
     int npart_max;
 };
@@ -134,6 +135,9 @@ static int ov_enc_splitk(int L, int B, int G) {
     const int smax = std::max(1, G / 256);
     return std::max(1, std::min(std::min(s, 128), smax));
 }
+
+// lanes of the gene layer's SELL form (ontovae_gsell_t): every window of 512 genes rounds up to whole slices of 64
+static inline int64_t ov_gsell_lanes_max(int64_t G) { return (G + 511) / 512 * 512; }
 
 // rows a training entry point may take: ctx->max_train_batch, or max_batch if that is 0
 static inline int ov_train_cap(const ontovae_ctx_t* c) {
@@ -177,6 +181,7 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, int train_batch,
     w.kl_part = take(npart);
     w.wpart = take((tldb / 32) * ((int64_t)d.nnz + C + G));
     w.wgene = take((int64_t)d.nnz - d.nnz_term);
+    w.gb4 = take((tldb / 4) * ov_gsell_lanes_max(d.G));
     w.slab_floats = slab;
     w.npart_max = (int)npart;
     if (ws) *ws = w;
@@ -493,13 +498,13 @@ struct OvRefresh {
     const int32_t* kf; float* wf; int nf;
     const int32_t* nodef; float* biasf; int nbf;
     const int32_t* kb; float* wb; int nb;
-    const int32_t* kg; float* wg; int ng;      // gene layer: weights in CSR order (what the forward gene kernels walk) <- packed order
+    const int32_t* kg; float* wg; int ng;      // gene layer: weights in the order the pass's forward gene kernel walks (CSR, or the SELL form) <- packed order
 };
 __device__ __forceinline__ void ov_sell_refresh_part(const OvRefresh& r, int first, int stride) {
     for (int i = first; i < r.nf; i += stride) { const int k = r.kf[i]; r.wf[i] = k >= 0 ? r.vals[k] : 0.f; }
     for (int i = first; i < r.nbf; i += stride) { const int n = r.nodef[i]; r.biasf[i] = n >= 0 ? r.bias[n] : 0.f; }
     for (int i = first; i < r.nb; i += stride) { const int k = r.kb[i]; r.wb[i] = k >= 0 ? r.vals[k] : 0.f; }
-    for (int i = first; i < r.ng; i += stride) r.wg[i] = r.vals[r.kg[i]];
+    for (int i = first; i < r.ng; i += stride) { const int k = r.kg[i]; r.wg[i] = k >= 0 ? r.vals[k] : 0.f; }
 }
 
 __global__ __launch_bounds__(256) void ov_reparam_kernel(float* __restrict__ mulv, const float* __restrict__ eps,
@@ -1572,6 +1577,122 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
     }
 }
 
+// Gene layer forward of a training pass against an LDS panel (batches of 512 columns and more).  The 32-column-block kernel
+// above gathers one 128-B row piece per link from the L2: 2 requests of 64 B per link and block, 261 M per pass at 8192
+// columns of GO-BP, and that request rate (0.2 T/s, three quarters of what the 128 L2 channels take) is what bounds it.  Here a
+// workgroup keeps the 4 columns of ALL C panel rows in LDS (C x 16 B, as the chain kernels do), walks the gene lists in
+// SELL-64 order (ontovae_gsell_t: one gene per lane, 4 links per 8-B + 16-B load, every load of a wave one contiguous piece)
+// and takes the panel rows from LDS: the L2 then sees 6.9 B per link and column group instead of 16 B x 8 lanes per link and
+// block, 0.64x the requests in all (the 16-B pieces of D and of the panel load each cost a whole request).
+// Workgroup = (column group, chunk of slices); the 8 column groups of a 128-B line of D sit on one XCD in consecutive
+// workgroups and walk the slices in the same fixed rotation, so that their 16-B pieces meet in that L2 (with slices handed
+// out by a shared counter the HBM saw 1.6 GB of writes instead of 0.9 GB).  Every per-slice result is independent of the
+// wave that computed it, and the sums of squares are combined in slice order.
+// gb4 != NULL: [column group][lane of the SELL form] sums of D over the group's 4 columns, the gene bias gradient's
+// partials (ov_wgrad_finish_body adds the groups in order).
+struct OvGeneLds {
+    const int32_t* gene; const int32_t* quad0; const uint2* col; const f32x4* w; int n_slices;
+    const float* bias; const float* act; float* d; int B, ldb, C;
+    const float* x; const int32_t* xidx; int64_t xld;
+    float* rec_part; float* gb4; int nl;
+    int ncg, spc, nunits;        // column groups (ldb / 4), slices per chunk, (chunk, 8 column groups) units
+};
+__global__ __launch_bounds__(1024) void ov_gene_lds_kernel(const OvGeneLds a) {
+    extern __shared__ __attribute__((aligned(16))) float ov_panel[];
+    const int tid = threadIdx.x, lane = ov_lane(), wave = ov_wave_id();
+    const int wg = blockIdx.x, xcd = wg & 7, idx = wg >> 3;
+    const int unit = (idx >> 3) * 8 + xcd;
+    if (unit >= a.nunits) {                        // workgroup-uniform
+        if (tid == 0) a.rec_part[wg] = 0.f;
+        return;
+    }
+    const int opc = a.ncg >> 3;
+    const int chunk = unit / opc, cg = (unit - chunk * opc) * 8 + (idx & 7);
+    const int col0 = cg * 4;
+    const int s0 = chunk * a.spc, s1 = min(s0 + a.spc, a.n_slices);
+    const bool active = col0 < a.B;                // else a group of padding columns: zero rows of D, nothing else
+    f32x4* panel = reinterpret_cast<f32x4*>(ov_panel);
+    float* sq_s = ov_panel + (size_t)a.C * 4;      // [spc] sums of squares per slice
+    if (active) {
+        int n = tid;
+        for (; n + 3072 < a.C; n += 4096) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(a.act + (int64_t)n * a.ldb + col0);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(a.act + (int64_t)(n + 1024) * a.ldb + col0);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(a.act + (int64_t)(n + 2048) * a.ldb + col0);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(a.act + (int64_t)(n + 3072) * a.ldb + col0);
+            panel[n] = v0; panel[n + 1024] = v1; panel[n + 2048] = v2; panel[n + 3072] = v3;
+        }
+        for (; n < a.C; n += 1024) panel[n] = *reinterpret_cast<const f32x4*>(a.act + (int64_t)n * a.ldb + col0);
+    }
+    int64_t xr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = col0 + c;
+        xr[c] = col < a.B ? (a.xidx ? (int64_t)a.xidx[col] : (int64_t)col) * a.xld : -1;
+    }
+    __syncthreads();
+    int iter = 0;
+    for (int sl = s0 + wave; sl < s1; ++iter, sl = s0 + 16 * iter + ((wave + iter) & 15)) {
+        const int g = a.gene[sl * 64 + lane];
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        float sq = 0.f;
+        if (active) {
+            float xv[4] = {0.f, 0.f, 0.f, 0.f};
+            float bv = 0.f;
+            if (g >= 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (xr[c] >= 0) xv[c] = a.x[xr[c] + g];
+                bv = a.bias[a.C + g];
+            }
+            const int q0 = __builtin_amdgcn_readfirstlane(a.quad0[sl]);
+            const int nq = __builtin_amdgcn_readfirstlane(a.quad0[sl + 1]) - q0;
+            const uint2* cp = a.col + (int64_t)q0 * 64 + lane;
+            const f32x4* wp = a.w + (int64_t)q0 * 64 + lane;
+            f32x4 acc = {bv, bv, bv, bv};
+            auto fetch = [&](int i, uint2& c, f32x4& w) {
+                if (i < nq) { c = cp[i * 64]; w = wp[i * 64]; }
+                else { c = make_uint2(0u, 0u); w = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            };
+            auto use = [&](const uint2 c, const f32x4 w) {
+                const f32x4 p0 = panel[c.x & 0xffffu], p1 = panel[c.x >> 16], p2 = panel[c.y & 0xffffu], p3 = panel[c.y >> 16];
+                acc += w.x * p0;
+                acc += w.y * p1;
+                acc += w.z * p2;
+                acc += w.w * p3;
+            };
+            uint2 c0, c1, nc0, nc1;
+            f32x4 w0, w1, nw0, nw1;
+            fetch(0, c0, w0);
+            fetch(1, c1, w1);
+            for (int i = 0; i < nq; i += 2) {
+                fetch(i + 2, nc0, nw0);
+                fetch(i + 3, nc1, nw1);
+                use(c0, w0);
+                use(c1, w1);
+                c0 = nc0; w0 = nw0; c1 = nc1; w1 = nw1;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (g >= 0 && xr[c] >= 0) {
+                    const float dv = acc[c] - xv[c];
+                    sq += dv * dv;
+                    o[c] = 2.f * dv;
+                }
+        }
+        if (g >= 0) *reinterpret_cast<f32x4*>(a.d + (int64_t)(a.C + g) * a.ldb + col0) = o;
+        if (active && a.gb4) a.gb4[(int64_t)cg * a.nl + sl * 64 + lane] = (o.x + o.y) + (o.z + o.w);
+        sq = ov_wave_sum(sq);
+        if (lane == 0) sq_s[sl - s0] = sq;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float t = 0.f;
+        for (int i = lane; i < s1 - s0; i += 64) t += sq_s[i];
+        t = ov_wave_sum(t);
+        if (lane == 0) a.rec_part[wg] = t;
+    }
+}
+
 // Gene part of the backward on 32-column blocks: D[p, cols] = sum over the genes g of column p of W[g, p] * D[g, cols].
 // 4 waves, 32 panel nodes per workgroup, one node per lane group.
 // wpart != NULL: also the weight-gradient partials of the gene layer's links, part[cb][k] (ov_gather_grp_wgrad).
@@ -1739,6 +1860,8 @@ struct OvFinishArgs {
     int apply_update; OvAdam adam;
     int64_t nnz_term;
     int sel;        // 0: everything; 1: the gene layer's links and biases only; 2: the term layers' only (nnz_term must be set)
+    // gene rows' bias partials as ov_gene_lds_kernel leaves them: gb4[group][lane] over ngrp column groups, the lane's gene in lane_gene
+    const float* gb4; const int32_t* lane_gene; int nl, ngrp;
 };
 // first / stride: this thread's number and the thread count of the finish part
 __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, const int64_t first, const int64_t stride) {
@@ -1767,11 +1890,7 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
         for (; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
         update(k, g);
     }
-    const int rb = terms ? 0 : a.n_term_rows, re = genes ? a.nrows : a.n_term_rows;
-    for (int64_t r = rb + first; r < re; r += stride) {
-        float g = 0.f;
-        for (int cb = 0; cb < a.ncb; ++cb) g += a.bpart[(int64_t)cb * a.nrows + r];
-        const int node = r < a.n_term_rows ? a.first_term_node + (int)r : a.C + ((int)r - a.n_term_rows);
+    auto update_bias = [&](int node, float g) {
         if (a.apply_update) {
             float w = a.bias[node], m = a.mbias[node], v = a.vbias[node];
             ov_adamw(w, m, v, g, a.adam, false);
@@ -1779,6 +1898,39 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
         } else {
             a.gbias[node] = g;
         }
+    };
+    if (genes && a.gb4) {
+        // 16 lanes of the SELL form per wave, the column groups in 4 runs: every load of a wave is 4 pieces of 64 B, and four
+        // times as many threads walk runs a quarter as long (2048 groups at 8192 columns); run sums are added in run order
+        const int ii = (int)(first & 15), seg = (int)((first >> 4) & 3);
+        const int per = (a.ngrp + 3) / 4, c0 = seg * per, c1 = min(c0 + per, a.ngrp);
+        for (int64_t i0 = (first >> 6) * 16; i0 < a.nl; i0 += (stride >> 6) * 16) {        // wave-uniform trip count
+            const int64_t i = i0 + ii;
+            float g = 0.f;
+            if (i < a.nl) {
+                int cg = c0;
+                for (; cg + 8 <= c1; cg += 8) {
+                    float t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = a.gb4[(int64_t)(cg + j) * a.nl + i];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g += t[j];
+                }
+                for (; cg < c1; ++cg) g += a.gb4[(int64_t)cg * a.nl + i];
+            }
+            const float g1 = __shfl(g, ii + 16, 64), g2 = __shfl(g, ii + 32, 64), g3 = __shfl(g, ii + 48, 64);
+            if (seg == 0 && i < a.nl) {
+                const int gene = a.lane_gene[i];
+                if (gene >= 0) update_bias(a.C + gene, ((g + g1) + g2) + g3);
+            }
+        }
+    }
+    const int rb = terms ? 0 : a.n_term_rows, re = (genes && !a.gb4) ? a.nrows : a.n_term_rows;
+    for (int64_t r = rb + first; r < re; r += stride) {
+        float g = 0.f;
+        for (int cb = 0; cb < a.ncb; ++cb) g += a.bpart[(int64_t)cb * a.nrows + r];
+        const int node = r < a.n_term_rows ? a.first_term_node + (int)r : a.C + ((int)r - a.n_term_rows);
+        update_bias(node, g);
     }
 }
 __global__ __launch_bounds__(256) void ov_wgrad_finish_kernel(const OvFinishArgs a) {
@@ -2286,6 +2438,7 @@ struct OvStep {
     // training, column-block kernels: the gene layer's weight gradient is formed inside the gene-layer kernels themselves
     // (bias partials in the forward kernel, link partials in the backward kernel); NULL = not wanted
     float* gw_part; float* gw_bpart; int gw_rows, gw_row0;
+    bool gene_lds;           // the gene layer's forward of this pass is ov_gene_lds_kernel (entry points that compute the loss set it)
 };
 
 // Independent branches of a step run on a library-owned second stream, forked from and joined back into
@@ -2460,6 +2613,7 @@ static bool ov_gene_refresh_rides(const OvStep& s) {
 static void ov_gene_refresh_args(const OvStep& s, OvRefresh* r) {
     const ontovae_ctx_t* c = s.c;
     r->vals = c->P + c->lay.dec_vals;
+    if (s.gene_lds) { r->kg = c->gsell.k; r->wg = c->gsell.w; r->ng = c->gsell.n_quads * 256; return; }
     r->kg = c->row_k + c->dims.nnz_term; r->wg = s.ws.wgene; r->ng = (int)(c->dims.nnz - c->dims.nnz_term);
 }
 // arguments of the refresh of the re-ordered weight copies: SELL order of the term layers (only if this model uses the fused
@@ -2609,11 +2763,56 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     return ONTOVAE_OK;
 }
 
+// geometry of ov_gene_lds_kernel for this pass
+struct OvGeneLdsGeo { int ncg, nchunk, spc, nunits, grid; size_t lds; };
+static OvGeneLdsGeo ov_gene_lds_geo(const OvStep& s) {
+    const ontovae_gsell_t& g = s.c->gsell;
+    OvGeneLdsGeo q;
+    q.ncg = s.ldb / 4;
+    // two chunks of slices where the column groups alone leave CUs idle (every chunk loads the whole panel)
+    const int nchunk = (q.ncg < 192 && g.n_slices >= 128) ? 2 : 1;
+    q.spc = (g.n_slices + nchunk - 1) / nchunk;
+    q.nchunk = (g.n_slices + q.spc - 1) / q.spc;
+    q.nunits = q.nchunk * (q.ncg / 8);
+    q.grid = (q.nunits + 7) / 8 * 64;
+    q.lds = (size_t)s.c->dims.C * 16 + (size_t)q.spc * sizeof(float);      // panel, sums of squares per slice
+    return q;
+}
+// the loss-computing forward of the gene layer goes through the LDS-panel kernel
+static bool ov_gene_cb_on(const OvStep& s);
+static bool ov_gene_lds_on(const OvStep& s) {
+    const ontovae_ctx_t* c = s.c;
+    const ontovae_gsell_t& g = c->gsell;
+    if (c->flags & ONTOVAE_FLAG_CB_GENE_FWD) return false;
+    if (!ov_gene_cb_on(s)) return false;
+    if (g.n_slices < 1 || g.n_quads < 0 || !g.gene || !g.quad0 || !g.col || !g.k || !g.w) return false;
+    if ((int64_t)g.n_slices * 64 > ov_gsell_lanes_max(c->dims.G) || c->dims.C > 65535) return false;
+    // from 512 columns on: below, (column group, chunk) workgroups that each load the whole panel are too many for what they
+    // then do, and the 32-column-block kernel is faster (27 against 23 us at 128 columns)
+    if (s.ldb < 512) return false;
+    return ov_gene_lds_geo(s).lds <= (size_t)160 * 1024 - 64;
+}
+
 // gene layer: tiled kernel when x can be read in aligned 16-B pieces, row-per-wave kernel otherwise
 template <int MODE>
 static int ov_dec_gene(OvStep& s, float* rec_out, int64_t rec_ld) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
+    if (MODE == 1 && s.gene_lds) {
+        const ontovae_gsell_t& g = c->gsell;
+        const OvGeneLdsGeo q = ov_gene_lds_geo(s);
+        // the bias partials only where the training buffers hold this batch (a loss-only pass has no use for them)
+        float* gb4 = s.gw_bpart ? s.ws.gb4 : nullptr;
+        const OvGeneLds a{g.gene, g.quad0, reinterpret_cast<const uint2*>(g.col), reinterpret_cast<const f32x4*>(g.w), g.n_slices,
+                          c->P + c->lay.dec_bias, s.ws.act, s.ws.d, s.B, s.ldb, d.C, s.x, s.xidx, s.xld, s.ws.rec_part, gb4,
+                          g.n_slices * 64, q.ncg, q.spc, q.nunits};
+        int rc;
+        OvProfScope prof(ONTOVAE_PHASE_DEC_FWD_GENE, s.st);
+        if ((rc = ov_set_lds(ov_gene_lds_kernel, q.lds))) return rc;
+        hipLaunchKernelGGL(ov_gene_lds_kernel, dim3(q.grid), dim3(1024), q.lds, s.st, a);
+        OV_LAUNCH_CHECK();
+        return ONTOVAE_OK;
+    }
     bool tiled = (d.G % 4 == 0) && !(c->flags & ONTOVAE_FLAG_ROW_GENE_LAYER);
     if (MODE == 1) tiled = tiled && ov_al16(s.x) && (s.xld % 4 == 0);
     if (MODE == 2) tiled = tiled && ov_al16(rec_out) && (rec_ld % 4 == 0);
@@ -2648,6 +2847,7 @@ static bool ov_gene_cb_on(const OvStep& s) {
 // number of sum-of-squares partials the gene layer wrote (must match ov_dec_gene<1>)
 static int ov_nrec(const OvStep& s) {
     const ontovae_dims_t& d = s.c->dims;
+    if (s.gene_lds) return ov_gene_lds_geo(s).grid;
     const bool tiled = (d.G % 4 == 0) && !(s.c->flags & ONTOVAE_FLAG_ROW_GENE_LAYER) && ov_al16(s.x) && (s.xld % 4 == 0);
     if (tiled && !(s.c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) return ov_cb_grid(s.ldb / 32, (d.G + 31) / 32);
     return (tiled ? (d.G + OV_GT_GENES - 1) / OV_GT_GENES : (d.G + 3) / 4) * s.nchunk;
@@ -2748,6 +2948,7 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->fm_ld = 0;
     s->want_xT = false;
     s->gw_part = nullptr; s->gw_bpart = nullptr; s->gw_rows = 0; s->gw_row0 = 0;
+    s->gene_lds = false;
     return ONTOVAE_OK;
 }
 
@@ -2801,6 +3002,7 @@ extern "C" int ontovae_eval_step(const ontovae_ctx_t* ctx, const float* x, const
     if (!x || !loss_out) { ontovae_set_error("eval_step: x or loss_out is NULL"); return ONTOVAE_EINVAL; }
     OvStep s;
     ov_make_step(ctx, x, xidx, B, stream, &s);
+    s.gene_lds = ov_gene_lds_on(s);
     int nkl = 0;
     if ((rc = ov_encode(s, eps, 0, rng_offset, OV_RNG_EPS, 1, &nkl))) return rc;
     if ((rc = ov_dec_forward_terms(s, true))) return rc;
@@ -3059,7 +3261,8 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                           c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                           G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
                           c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam,
-                          d.nnz_term, 0};
+                          d.nnz_term, 0, nullptr, nullptr, 0, 0};
+        if (s.gene_lds && fused_gw) { fa.gb4 = s.ws.gb4; fa.lane_gene = c->gsell.gene; fa.nl = c->gsell.n_slices * 64; fa.ngrp = (s.B + 3) / 4; }
         // only while the chain leaves most of the chip idle (<= 128 workgroups): at larger batches the chain's workgroups
         // fill every CU themselves and 1024-thread riders next to their LDS reservation only stretch the launch
         ride_fin = fused_gw && s.ldb / std::max(ov_fused_bt(c), 1) <= 128;
@@ -3234,6 +3437,7 @@ extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, cons
     OvStep s;
     ov_make_step(ctx, x, xidx, B, stream, &s);
     s.want_xT = true;
+    s.gene_lds = ov_gene_lds_on(s);
     s.side = ov_side_get(ctx);
     bool refreshed = false;
     if (s.side && ov_fused_bt(ctx) != 0 && OV_DBG((ctx->flags & 32u) != 0)) {      // packed decoder weight copies || encoder (measurement only)
@@ -3259,6 +3463,7 @@ extern "C" int ontovae_train_step_dp(const ontovae_ctx_t* ctx, int32_t phase, co
     OvStep s;
     ov_make_step(ctx, x, xidx, B, stream, &s);
     s.want_xT = true;
+    s.gene_lds = ov_gene_lds_on(s);
     if (phase == 0) {
         int S = 1;
         if ((rc = ov_enc_gemm(s, &S))) return rc;

@@ -159,6 +159,9 @@ class Engine:
             dv["w"] = torch.zeros(max(sd["n_chunks"], 1) * 512, dtype=torch.float32, device=dev)
             dv["bias"] = torch.zeros(max(sd["n_slices"], 1) * 64, dtype=torch.float32, device=dev)
             self._sell.append(dv)
+        gs = p.gsell
+        self._gsell = {f: t(gs[f].view(np.int16) if f == "col" else gs[f]) for f in ("gene", "quad0", "col", "k")}
+        self._gsell["w"] = torch.zeros(max(gs["n_quads"], 1) * 256, dtype=torch.float32, device=dev)
         self._idx = dict(rowptr=t(p.rowptr), colidx=t(p.colidx), cscptr=t(p.cscptr), csc_row=t(p.csc_row),
                          csc_k=t(p.csc_k), csc_split=t(p.csc_split), row_k=t(p.row_k), er=t(p.entry_row), ec=t(p.entry_col))
         self._ctx = None
@@ -239,6 +242,9 @@ class Engine:
                 t.level_count = sd["level_count"].ctypes.data_as(_lib.c_i32p)
                 for f in ("node", "info", "chunk0", "idx", "k", "w", "bias"):
                     setattr(t, f, _ptr(dev[f]))
+            c.gsell.n_slices, c.gsell.n_quads = self.plan.gsell["n_slices"], self.plan.gsell["n_quads"]
+            for f in ("gene", "quad0", "col", "k", "w"):
+                setattr(c.gsell, f, _ptr(self._gsell[f]))
             base = self._ws.data_ptr()
             aligned = (base + 255) // 256 * 256
             c.workspace = C.c_void_p(aligned)

@@ -69,6 +69,15 @@ class MaskPlan:
         self.row_k = np.zeros(n, dtype=np.int32)
         _lib.check(L.ontovae_plan_row_k(handle, _i32p(self.row_k)), "plan row_k")
         self.sell = [self._export_sell(d) for d in (0, 1)]
+        # SELL-64 form of the gene layer (ontovae_gsell_t): one gene per lane, lists in quads of 4 entries
+        ns, nq = C.c_int32(), C.c_int32()
+        _lib.check(L.ontovae_plan_gsell_sizes(handle, C.byref(ns), C.byref(nq)), "gsell sizes")
+        self.gsell = dict(n_slices=ns.value, n_quads=nq.value, gene=np.full(max(ns.value, 1) * 64, -1, dtype=np.int32),
+                          quad0=np.zeros(ns.value + 1, dtype=np.int32), col=np.zeros(max(nq.value, 1) * 256, dtype=np.uint16),
+                          k=np.full(max(nq.value, 1) * 256, -1, dtype=np.int32))
+        _lib.check(L.ontovae_plan_gsell_export(handle, _i32p(self.gsell["gene"]), _i32p(self.gsell["quad0"]),
+                                               self.gsell["col"].ctypes.data_as(C.POINTER(C.c_uint16)), _i32p(self.gsell["k"])),
+                   "gsell export")
         self.entry_layer = np.zeros(n, dtype=np.int32)
         self.entry_row = np.zeros(n, dtype=np.int32)
         self.entry_col = np.zeros(n, dtype=np.int32)

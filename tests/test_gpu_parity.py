@@ -386,8 +386,8 @@ def test_train_vs_oracle_batch_sizes(B):
     check_params(hip_state(model), o.state_dict(), 3 * lr, rtol=2e-4, atol=2e-6, outliers=0.01)
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8, 16, 8 | 1])
-@pytest.mark.parametrize("B", [128, 200, 37])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8, 16, 8 | 1, 128, 128 | 16, 128 | 4])
+@pytest.mark.parametrize("B", [128, 200, 37, 530])
 def test_gradients_vs_oracle(B, flags):
     """Raw gradients (apply_update=0 -> flat buffer) against the oracle's hand-written backward:
     every tensor within 2e-5 of its own scale (fp32 summation-order noise is ~2e-6)."""
@@ -402,7 +402,8 @@ def test_gradients_vs_oracle(B, flags):
     model, _ = make_model(masks, 3, sd)
     e = model._engine
     # 1: per-level launches, 2: row-per-wave gene layer (the general-purpose variants), 4: side stream,
-    # 8: wide gene-layer tiles instead of 32-column blocks, 16: no riders in the backward chain's launch
+    # 8: wide gene-layer tiles instead of 32-column blocks, 16: no riders in the backward chain's launch,
+    # 128: the gene layer's training forward on 32-column blocks instead of the LDS-panel kernel (0 runs that one)
     e.flags = flags
     e.invalidate()
     out = torch.zeros(3, device="cuda")
@@ -424,6 +425,31 @@ def test_gradients_vs_oracle(B, flags):
         assert np.abs(v.cpu().numpy() - want).max() <= 2e-5 * scale, k
     # the Linear bias in front of a train-mode BatchNorm has an analytically zero gradient
     assert np.abs(e.view("b0", G).cpu().numpy()).max() <= 1e-4 * np.abs(g["encoder.encoder.0.1.bias"]).max()
+
+
+def test_lds_panel_gene_forward_matches_block_kernel_and_repeats_bitwise():
+    """From 512 columns on the training forward of the gene layer walks SELL-ordered lists against an LDS panel
+    (ov_gene_lds_kernel); flag 128 keeps the 32-column-block kernel.  Same model, same batch: the two agree to summation-order
+    noise in loss and every gradient, and the LDS-panel path gives the same bits when run twice (fixed slice rotation, sums in
+    slice order)."""
+    masks, sd = medium()
+    B = 777
+    rng = np.random.RandomState(5)
+    x = torch.as_tensor(np.log1p(rng.poisson(0.5, size=(B, 1000))).astype(np.float32))
+    eps = torch.as_tensor(rng.standard_normal((B, 60)).astype(np.float32))
+    runs = []
+    for flags in (0, 0, 128):
+        model, _ = make_model(masks, 3, sd)
+        e = model._engine
+        e.flags = flags
+        e.invalidate()
+        out = torch.zeros(3, device="cuda")
+        e.train_step(x, None, eps, 1e-4, None, out, apply_update=False)
+        runs.append((out.cpu().numpy(), e.Gr.cpu().numpy().copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    np.testing.assert_allclose(runs[0][0], runs[2][0], rtol=2e-6)
+    scale = np.abs(runs[2][1]).max()
+    assert np.abs(runs[0][1] - runs[2][1]).max() <= 2e-6 * scale
 
 
 @pytest.mark.parametrize("counts,nu", [((400, 900, 1300, 1000), 3), ((3000, 5000, 6000, 4000, 2500), 2)])

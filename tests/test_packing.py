@@ -52,6 +52,38 @@ def check_plan(masks, nu):
     for p in range(C):  # rows ascend inside a column
         seg = plan.csc_row[plan.cscptr[p]:plan.cscptr[p + 1]]
         assert np.all(np.diff(seg) > 0)
+    # SELL form of the gene layer: every gene owns one lane, its quads hold exactly the (panel row, packed position) pairs of
+    # its CSR list, padding has k = -1; genes of a slice come from one window of 512 and lists shorten along a window
+    gs = plan.gsell
+    if C <= 65535:
+        lanes = gs["gene"][:gs["n_slices"] * 64]
+        assert sorted(lanes[lanes >= 0].tolist()) == list(range(plan.G))
+        col = gs["col"][:gs["n_quads"] * 256].reshape(-1, 64, 4)
+        kk = gs["k"][:gs["n_quads"] * 256].reshape(-1, 64, 4)
+        assert int((kk >= 0).sum()) == plan.nnz - nnz_term
+        prev_len = {}
+        for sl in range(gs["n_slices"]):
+            q0, q1 = gs["quad0"][sl], gs["quad0"][sl + 1]
+            gl = lanes[sl * 64:(sl + 1) * 64]
+            assert len({g // 512 for g in gl[gl >= 0].tolist()}) == 1
+            lens = []
+            for lane in range(64):
+                g = gl[lane]
+                c_, k_ = col[q0:q1, lane].reshape(-1), kk[q0:q1, lane].reshape(-1)
+                if g < 0:
+                    assert (k_ < 0).all()
+                    continue
+                j0, j1 = plan.rowptr[C + g], plan.rowptr[C + g + 1]
+                n = j1 - j0
+                assert np.array_equal(c_[:n], plan.colidx[j0:j1]) and np.array_equal(k_[:n], plan.row_k[j0:j1])
+                assert (k_[n:] < 0).all() and (c_[n:] == 0).all()
+                lens.append(n)
+            assert lens == sorted(lens, reverse=True) and q1 - q0 == (lens[0] + 3) // 4
+            w = gl[0] // 512
+            assert prev_len.get(w, 1 << 30) >= lens[0]
+            prev_len[w] = lens[-1]
+    else:
+        assert gs["n_slices"] == 0
     # levels tile the panel in reverse order and then the genes
     assert plan.level_begin[0] == C - plan.L and plan.level_end[0] == C
     for d in range(1, plan.K):
