@@ -1427,13 +1427,16 @@ __device__ __forceinline__ void ov_gather_grp_wgrad(f32x4& acc, int k0, int len,
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
     maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    // packed position of the list's first link; it ascends by 1 along the list (ontovae_plan_row_k), so the weight of entry e
+    // is one load at a known address, not a load behind the load of its position (25.2 -> 22.1 us at 128 columns)
+    const int kb = len > 0 ? kidx[k0] : 0;
     auto fetch = [&](int e, int& r, float& w, int& k) {
         const int ee = max(min(e, len - 1), 0);
         r = len > 0 ? rowidx[k0 + ee] : 0;
         w = 0.f;
         k = -1;
-        if (e < len) {          // k: the link's packed position (ascending by 1 along the list: ontovae_plan_row_k)
-            k = kidx[k0 + e];
+        if (e < len) {
+            k = kb + e;
             w = vals[k];
         }
     };
@@ -1696,7 +1699,8 @@ __global__ __launch_bounds__(1024) void ov_gene_lds_kernel(const OvGeneLds a) {
 // Gene part of the backward on 32-column blocks: D[p, cols] = sum over the genes g of column p of W[g, p] * D[g, cols].
 // 4 waves, 32 panel nodes per workgroup, one node per lane group.
 // wpart != NULL: also the weight-gradient partials of the gene layer's links, part[cb][k] (ov_gather_grp_wgrad).
-__global__ __launch_bounds__(256) void ov_bwd_gene_cb_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_split,
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ov_bwd_gene_cb_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_split,
                                                             const int32_t* __restrict__ csc_row, const int32_t* __restrict__ csc_k,
                                                             const float* __restrict__ vals, float* __restrict__ d,
                                                             float* __restrict__ dblk, int C, int ldb, int ncb, int ntiles,
@@ -2887,8 +2891,14 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
         const int ncb = s.ldb / 32, ntiles = (d.C + 31) / 32;
         if (bt == 4) blk = s.ws.dblk;           // the chain's workgroups take 4 columns each: hand them contiguous pieces
-        hipLaunchKernelGGL(ov_bwd_gene_cb_kernel, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row,
-                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles, s.ws.act, s.gw_part, (int64_t)d.nnz, 0);
+        // waves per SIMD: the kernel needs 5 to cover its latencies while 4 column blocks are all there is (22.1 us at 128
+        // columns against 24.7 with 4); once every XCD works through many blocks, fewer waves leave more of its L2 to each
+        // (1024 columns: 170 us with 4 against 176 with 5; 8192: 1.40 ms with 3, 1.43 with 4, 1.52 with 5)
+        const int wpe = s.ldb >= 4096 ? 3 : (s.ldb >= 1024 ? 4 : 5);
+#define OV_BG_CB(W) hipLaunchKernelGGL(ov_bwd_gene_cb_kernel<W>, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row, \
+                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles, s.ws.act, s.gw_part, (int64_t)d.nnz, 0)
+        if (wpe == 3) OV_BG_CB(3); else if (wpe == 4) OV_BG_CB(4); else OV_BG_CB(5);
+#undef OV_BG_CB
         OV_LAUNCH_CHECK();
     } else {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);

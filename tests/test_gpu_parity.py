@@ -452,6 +452,29 @@ def test_lds_panel_gene_forward_matches_block_kernel_and_repeats_bitwise():
     assert np.abs(runs[0][1] - runs[2][1]).max() <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("flags", [0, 128])
+def test_eval_step_large_batch_vs_oracle(flags):
+    """val_round's body (vae_model.py:194-198) on 777 rows: eval-mode BatchNorm, no dropout, loss only.  From 512 columns on
+    the gene layer runs the LDS-panel kernel without its bias partials (a loss-only pass has no training buffers)."""
+    from ontovae_oracle import OracleOntoVAE
+    masks, sd = medium()
+    B = 777
+    rng = np.random.RandomState(6)
+    x = np.log1p(rng.poisson(0.5, size=(B, 1000))).astype(np.float32)
+    eps = rng.standard_normal((B, 60)).astype(np.float32)
+    o = OracleOntoVAE(masks, 3)
+    o.load_state_dict(sd)
+    want = o.val_step(x, eps, 1e-4)
+    model, _ = make_model(masks, 3, sd)
+    model.eval()
+    e = model._engine
+    e.flags = flags
+    e.invalidate()
+    out = torch.zeros(3, device="cuda")
+    e.eval_step(torch.as_tensor(x).cuda(), None, torch.as_tensor(eps).cuda(), 1e-4, out)
+    np.testing.assert_allclose(out.cpu().numpy(), np.array(want, dtype=np.float32), rtol=REL)
+
+
 @pytest.mark.parametrize("counts,nu", [((400, 900, 1300, 1000), 3), ((3000, 5000, 6000, 4000, 2500), 2)])
 def test_large_panels_two_and_one_columns_per_workgroup(counts, nu):
     """Panels that do not fit LDS at 4 batch columns per workgroup (C = 10800 -> 2 columns, C = 41000 -> 1 column,
