@@ -452,6 +452,35 @@ def test_lds_panel_gene_forward_matches_block_kernel_and_repeats_bitwise():
     assert np.abs(runs[0][1] - runs[2][1]).max() <= 2e-6 * scale
 
 
+def test_dw0_of_a_batch_whose_row_indices_do_not_fit_lds():
+    """dW0 walks the batch in chunks; the pipelined kernel keeps the whole batch's row indices in LDS (up to ~22 k rows),
+    larger batches take ov_dw0_multi_kernel.  23 100 rows of the medium model against the oracle: loss and W0's gradient,
+    the float64 instance of the oracle as the yardstick (a sum over 23 100 rows in float32 is 1e-4 of its scale away from it
+    whoever forms it): the HIP path may miss it by at most twice what the float32 oracle misses it by."""
+    from ontovae_oracle import OracleOntoVAE
+    masks, sd = medium()
+    B = 23100
+    rng = np.random.RandomState(8)
+    x = np.log1p(rng.poisson(0.5, size=(B, 1000))).astype(np.float32)
+    eps = rng.standard_normal((B, 60)).astype(np.float32)
+    o = OracleOntoVAE(masks, 3)
+    o.load_state_dict(sd)
+    rec, kl, loss, g = o.gradients(x, eps, 1e-4)
+    model, _ = make_model(masks, 3, sd)
+    e = model._engine
+    out = torch.zeros(3, device="cuda")
+    e.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), 1e-4, None, out, apply_update=False)
+    np.testing.assert_allclose(out.cpu().numpy(), [rec, kl, loss], rtol=REL)
+    o64 = OracleOntoVAE(masks, 3, dtype=np.float64)
+    o64.load_state_dict(sd)
+    ref = o64.gradients(x, eps, 1e-4)[3]["encoder.encoder.0.0.weight"]
+    want = g["encoder.encoder.0.0.weight"]
+    got = e.view("W0", e.Gr).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= max(2 * np.abs(want - ref).max(), 2e-6 * scale)
+    assert np.abs(got - ref).max() <= 3e-4 * scale
+
+
 @pytest.mark.parametrize("flags", [0, 128])
 def test_eval_step_large_batch_vs_oracle(flags):
     """val_round's body (vae_model.py:194-198) on 777 rows: eval-mode BatchNorm, no dropout, loss only.  From 512 columns on
