@@ -131,9 +131,9 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // Fused AdamW (KW == 1): the tile's parameters and moments are requested BEFORE the K loop, so the
-    // optimizer's read traffic (the dominant HBM stream of dW0) runs under the MFMAs instead of after them.
-    constexpr bool PREF = (EPI == OV_EPI_ADAMW) && (KW == 1);
+    // Fused AdamW: the tile's parameters and moments are requested BEFORE the K loop, so the optimizer's read traffic runs
+    // under the MFMAs instead of after them (KW == 4: every wave for the quarter of the tile it ends up with).
+    constexpr bool PREF = (EPI == OV_EPI_ADAMW) && (KW == 1 || KW == 4);
     float pw[PREF ? MT : 1][PREF ? NT : 1][16], pm[PREF ? MT : 1][PREF ? NT : 1][16], pv[PREF ? MT : 1][PREF ? NT : 1][16];
     if (PREF && tile_on) {
 #pragma unroll
@@ -144,7 +144,7 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const bool ok = m < p.M && n < p.N;
+                    const bool ok = m < p.M && n < p.N && (KW != 4 || (r >> 2) == wave);
                     const int64_t idx = (int64_t)m * p.ldc + n;
                     pw[mt][nt][r] = ok ? p.C[idx] : 0.f;
                     pm[mt][nt][r] = ok ? p.Pm[idx] : 0.f;
@@ -248,28 +248,28 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
     }
 
     if (KW == 4) {
-        // combine the four K-quarters: waves 2, 3 -> LDS -> waves 0, 1; wave 1 -> LDS -> wave 0
+        // combine the four K-quarters: every wave leaves its partial tile in LDS and picks up one quarter of the tile
+        // (accumulator registers 4 w .. 4 w + 3: rows 8 w + {0..3} + 4 h), summed over the waves in wave order.  One
+        // barrier, and the epilogue (stores, or 3 loads + AdamW + 3 stores per element) is shared by the four waves
+        // instead of being wave 0's alone.
         constexpr int TT = MT * NT;
-        auto put = [&](int slot) {
 #pragma unroll
-            for (int t = 0; t < TT; ++t)
+        for (int t = 0; t < TT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[((slot * TT + t) * 16 + r) * 64 + lane] = acc[t / NT][t % NT][r];
-        };
-        auto add = [&](int slot) {
-#pragma unroll
-            for (int t = 0; t < TT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t / NT][t % NT][r] += red[((slot * TT + t) * 16 + r) * 64 + lane];
-        };
-        if (wave >= 2) put(wave - 2);
+            for (int r = 0; r < 16; ++r) red[((wave * TT + t) * 16 + r) * 64 + lane] = acc[t / NT][t % NT][r];
         __syncthreads();
-        if (wave < 2) add(wave);
-        __syncthreads();
-        if (wave == 1) put(0);
-        __syncthreads();
-        if (wave != 0) return;
-        add(0);
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * wave + q;
+                float v = red[((0 * TT + t) * 16 + r) * 64 + lane];
+                v += red[((1 * TT + t) * 16 + r) * 64 + lane];
+                v += red[((2 * TT + t) * 16 + r) * 64 + lane];
+                v += red[((3 * TT + t) * 16 + r) * 64 + lane];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) if (rr == r) acc[t / NT][t % NT][rr] = v;      // r is wave-uniform
+            }
     }
     if (!tile_on) return;
 
@@ -347,7 +347,7 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    ok[r] = m < p.M && n < p.N;
+                    ok[r] = m < p.M && n < p.N && (KW != 4 || (r >> 2) == wave);
                     const int64_t idx = (int64_t)m * p.ldc + n;
                     if (PREF) {
                         w[r] = pw[mt][nt][r]; mm[r] = pm[mt][nt][r]; vv[r] = pv[mt][nt][r];
@@ -358,7 +358,8 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ov_adamw(w[r], mm[r], vv[r], acc[mt][nt][r], p.adam, false);
+                for (int r = 0; r < 16; ++r)
+                    if (KW != 4 || (r >> 2) == wave) ov_adamw(w[r], mm[r], vv[r], acc[mt][nt][r], p.adam, false);      // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -369,7 +370,7 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < p.M && n < p.N) {
+                    if (m < p.M && n < p.N && (KW != 4 || (r >> 2) == wave)) {
                         const int64_t idx = (int64_t)m * p.ldc + n;
                         if (EPI == OV_EPI_STORE) p.C[(int64_t)bz * p.slab_stride + idx] = acc[mt][nt][r];
                         else p.C[idx] = acc[mt][nt][r] + p.bias[m];

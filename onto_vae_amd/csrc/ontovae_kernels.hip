@@ -2368,7 +2368,7 @@ static int ov_launch_gemm(const OvGemm& g, int S, bool vec, hipStream_t st) {
     const int bm = KW == 1 ? 64 * MT : 32 * MT, bn = KW == 1 ? 64 * NT : 32 * NT;
     dim3 grid((g.N + bn - 1) / bn, (g.M + bm - 1) / bm, S);
     size_t lds = 0;
-    if (KW == 4) lds = (size_t)2 * MT * NT * 16 * 64 * sizeof(float);
+    if (KW == 4) lds = (size_t)4 * MT * NT * 16 * 64 * sizeof(float);
     if (!B_KC && g.bgather) lds = std::max(lds, (size_t)std::min(g.K, g.kchunk) * sizeof(int32_t));
     if (EPI == OV_EPI_ADAMW_T) {
         if (KW != 1) { ontovae_set_error("gemm: the transposed AdamW epilogue needs KW == 1"); return ONTOVAE_EINVAL; }
@@ -3333,7 +3333,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         g.C = da_S > 1 ? s.ws.slab : s.ws.da; g.ldc = s.ldb; g.slab_stride = one; g.kchunk = kchunk;
         OvProfScope prof(ONTOVAE_PHASE_DA_GEMM, s.st);
         const int gx = (g.N + 31) / 32, gy = (g.M + 31) / 32;
-        const size_t lds = (size_t)2 * 16 * 64 * sizeof(float);        // KW == 4 reduction area of a 1 x 1 tile
+        const size_t lds = (size_t)4 * 16 * 64 * sizeof(float);        // KW == 4 reduction area of a 1 x 1 tile
         hipLaunchKernelGGL((ov_da_gemm_kernel<false>), dim3(gx * gy * da_S + (riders2 ? fblocks : 0)), dim3(256), lds, s.st, g, gx, gy,
                            da_S, fa, riders2 ? fblocks : 0);
         OV_LAUNCH_CHECK();
@@ -3359,7 +3359,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     if (!s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS)) {
         OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
         const int gx = (gw.N + 31) / 32, gy = (gw.M + 31) / 32;
-        const size_t lds = (size_t)2 * 16 * 64 * sizeof(float);
+        const size_t lds = (size_t)4 * 16 * 64 * sizeof(float);
         if (apply) hipLaunchKernelGGL((ov_dwh_bn_kernel<OV_EPI_ADAMW>), dim3(gx * gy + bn_blocks), dim3(256), lds, s.st, gw, gx, gy, bn);
         else hipLaunchKernelGGL((ov_dwh_bn_kernel<OV_EPI_STORE>), dim3(gx * gy + bn_blocks), dim3(256), lds, s.st, gw, gx, gy, bn);
         OV_LAUNCH_CHECK();
