@@ -161,6 +161,13 @@ typedef struct ontovae_gsell {
 int ontovae_plan_gsell_sizes(const ontovae_plan_t* plan, int32_t* n_slices, int32_t* n_quads);
 int ontovae_plan_gsell_export(const ontovae_plan_t* plan, int32_t* gene, int32_t* quad0, uint16_t* col, int32_t* k);
 
+/* Tiles of 32 rows as the column-block gene kernels take them: for every tile the 32 rows in order of decreasing list length,
+ * one record of 4 ints per slot {first list position, list length, row, packed position of the list's first link}.
+ * which = 0: gene tiles ([ceil(G / 32) * 32 * 4]; rows are genes, lists the CSR rows of the gene layer, unused slots have row G);
+ * which = 1: panel tiles ([ceil(C / 32) * 32 * 4]; rows are panel nodes, lists the gene part of their CSC columns, unused: row C).
+ * Optional in the context (NULL: every workgroup ranks its tile's rows itself, as before ABI 6). */
+int ontovae_plan_tile_info(const ontovae_plan_t* plan, int32_t which, int32_t* out);
+
 typedef struct ontovae_layout {
     int64_t W0;      /* [L, G]   encoder.encoder.0.0.weight                                   */
     int64_t b0;      /* [L]      encoder.encoder.0.0.bias                                     */
@@ -214,6 +221,8 @@ typedef struct ontovae_ctx {
     void* bf16_ws;
     int64_t bf16_ws_bytes;
     ontovae_gsell_t gsell;     /* n_slices == 0: not provided */
+    const int32_t* gene_tiles; /* device, ontovae_plan_tile_info(plan, 0), or NULL */
+    const int32_t* panel_tiles;/* device, ontovae_plan_tile_info(plan, 1), or NULL */
 } ontovae_ctx_t;
 
 #define ONTOVAE_FLAG_LEVEL_LAUNCHES 1u  /* one launch per decoder level instead of the LDS-fused chain */

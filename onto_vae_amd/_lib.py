@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ONTOVAE_HIP_LIB") or os.path.join(HERE, "libontovae_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -52,7 +52,7 @@ class Ctx(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_batch", C.c_int32), ("max_train_batch", C.c_int32),
                 ("drop", C.c_float), ("z_drop", C.c_float), ("seed", C.c_uint64), ("flags", C.c_uint32),
                 ("sell_fwd", Sell), ("sell_bwd", Sell), ("bf16_ws", C.c_void_p), ("bf16_ws_bytes", C.c_int64),
-                ("gsell", GSell)]
+                ("gsell", GSell), ("gene_tiles", C.c_void_p), ("panel_tiles", C.c_void_p)]
 
 
 VAE_MAXL = 8
@@ -112,6 +112,7 @@ def lib():
         "ontovae_plan_row_k": [vp, c_i32p],
         "ontovae_plan_sell_sizes": [vp, i32, c_i32p, c_i32p, c_i32p, c_i32p],
         "ontovae_plan_sell_export": [vp, i32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
+        "ontovae_plan_tile_info": [vp, i32, c_i32p],
         "ontovae_plan_gsell_sizes": [vp, c_i32p, c_i32p],
         "ontovae_plan_gsell_export": [vp, c_i32p, c_i32p, C.POINTER(C.c_uint16), c_i32p],
         "ontovae_plan_layer_node0": [vp, i32, c_i32p, c_i32p],
@@ -170,7 +171,7 @@ def lib():
 
 EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", "ontovae_plan_create_from_links",
             "ontovae_plan_destroy", "ontovae_plan_dims", "ontovae_plan_levels", "ontovae_plan_export",
-            "ontovae_plan_entry_coords", "ontovae_plan_csc_split", "ontovae_plan_row_k", "ontovae_plan_sell_sizes", "ontovae_plan_sell_export", "ontovae_plan_gsell_sizes", "ontovae_plan_gsell_export", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
+            "ontovae_plan_entry_coords", "ontovae_plan_csc_split", "ontovae_plan_row_k", "ontovae_plan_sell_sizes", "ontovae_plan_sell_export", "ontovae_plan_gsell_sizes", "ontovae_plan_gsell_export", "ontovae_plan_tile_info", "ontovae_plan_layer_node0", "ontovae_plan_unpack_mask", "ontovae_param_layout",
             "ontovae_workspace_bytes", "ontovae_workspace_bytes_split", "ontovae_bf16_workspace_bytes", "ontovae_forward", "ontovae_train_step", "ontovae_train_step_dp",
             "ontovae_adamw_apply", "ontovae_adamw_apply_range", "ontovae_dp_bn_bwd", "ontovae_dw0_rows", "ontovae_dw0_global", "ontovae_dp_pack_dy", "ontovae_dp_dh_global", "ontovae_eval_step", "ontovae_pass_data", "ontovae_decoder_forward",
             "ontovae_encode_pre", "ontovae_pass_data_perturbed",

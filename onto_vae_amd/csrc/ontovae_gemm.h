@@ -254,22 +254,22 @@ __device__ __forceinline__ void ov_gemm_body(const OvGemm& p, const int bx, cons
         // instead of being wave 0's alone.
         constexpr int TT = MT * NT;
 #pragma unroll
-        for (int t = 0; t < TT; ++t)
+        for (int t = 0; t < TT; ++t) {              // one 32 x 32 tile at a time: 16 KB of LDS whatever the workgroup tile
+            if (t > 0) __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave * TT + t) * 16 + r) * 64 + lane] = acc[t / NT][t % NT][r];
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < TT; ++t)
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t / NT][t % NT][r];
+            __syncthreads();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = 4 * wave + q;
-                float v = red[((0 * TT + t) * 16 + r) * 64 + lane];
-                v += red[((1 * TT + t) * 16 + r) * 64 + lane];
-                v += red[((2 * TT + t) * 16 + r) * 64 + lane];
-                v += red[((3 * TT + t) * 16 + r) * 64 + lane];
+                float v = red[(0 * 16 + r) * 64 + lane];
+                v += red[(1 * 16 + r) * 64 + lane];
+                v += red[(2 * 16 + r) * 64 + lane];
+                v += red[(3 * 16 + r) * 64 + lane];
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) if (rr == r) acc[t / NT][t % NT][rr] = v;      // r is wave-uniform
             }
+        }
     }
     if (!tile_on) return;
 

@@ -1421,7 +1421,7 @@ __device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const
 __device__ __forceinline__ void ov_gather_grp_wgrad(f32x4& acc, int k0, int len, const int32_t* __restrict__ rowidx,
                                                     const int32_t* __restrict__ kidx, const float* __restrict__ vals,
                                                     const float* __restrict__ srccol, int ldb, int lane, const f32x4 aseg,
-                                                    float* __restrict__ part) {
+                                                    float* __restrict__ part, const int kb_known = -1) {
     const int s = lane & 7;
     int maxlen = len;                    // wave maximum of len
 #pragma unroll
@@ -1429,7 +1429,7 @@ __device__ __forceinline__ void ov_gather_grp_wgrad(f32x4& acc, int k0, int len,
     maxlen = __builtin_amdgcn_readfirstlane(maxlen);
     // packed position of the list's first link; it ascends by 1 along the list (ontovae_plan_row_k), so the weight of entry e
     // is one load at a known address, not a load behind the load of its position (25.2 -> 22.1 us at 128 columns)
-    const int kb = len > 0 ? kidx[k0] : 0;
+    const int kb = kb_known >= 0 ? kb_known : (len > 0 ? kidx[k0] : 0);
     auto fetch = [&](int e, int& r, float& w, int& k) {
         const int ee = max(min(e, len - 1), 0);
         r = len > 0 ? rowidx[k0 + ee] : 0;
@@ -1502,7 +1502,8 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
                                                         const float* __restrict__ x, const int32_t* __restrict__ xidx, int G,
                                                         float* __restrict__ d, float* __restrict__ rec_part,
                                                         float* __restrict__ rec_out, int64_t rec_ld, int C, int ncb, int ntiles,
-                                                        float* __restrict__ bpart, int bp_rows, int bp_row0) {
+                                                        float* __restrict__ bpart, int bp_rows, int bp_row0,
+                                                        const int4* __restrict__ tiles) {
     constexpr int TG = 32, LD = 33;
     __shared__ float xs[TG * LD];
     __shared__ float red[4];
@@ -1518,10 +1519,15 @@ __global__ __launch_bounds__(256) void ov_gene_cb_kernel(const int32_t* __restri
     const int tid = threadIdx.x;
     const int s4 = 4 * (lane & 7);
     // the lists first: everything else waits on them
-    int my_k0 = 0, my_len = 0;
-    if (tid < 32 && g0 + tid < G) { my_k0 = rowptr[C + g0 + tid]; my_len = rowptr[C + g0 + tid + 1] - my_k0; }
-    int k0, len;
-    const int gl = ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
+    int k0, len, gl;
+    if (tiles) {                                   // the tile's rows ranked by list length, laid down by the plan
+        const int4 ti = tiles[map.tile * 32 + (tid >> 3)];
+        k0 = ti.x; len = ti.y; gl = ti.z - g0;
+    } else {
+        int my_k0 = 0, my_len = 0;
+        if (tid < 32 && g0 + tid < G) { my_k0 = rowptr[C + g0 + tid]; my_len = rowptr[C + g0 + tid + 1] - my_k0; }
+        gl = ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
+    }
     const int g = g0 + gl;
     const int node = C + min(g, G - 1);
     if (MODE == 1) {
@@ -1705,23 +1711,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                                                             const float* __restrict__ vals, float* __restrict__ d,
                                                             float* __restrict__ dblk, int C, int ldb, int ncb, int ntiles,
                                                             const float* __restrict__ act, float* __restrict__ wpart, int64_t nnz,
-                                                            int unused_) {
+                                                            const int4* __restrict__ tiles) {
     __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
     const OvCbMap map = ov_cb_map(blockIdx.x, ncb, ntiles);
     if (map.tile >= ntiles) return;
     const int lane = ov_lane();
     const int col0 = map.cb * 32, s4 = 4 * (lane & 7);
-    int my_k0 = 0, my_len = 0;
-    if (threadIdx.x < 32) {
-        const int node = map.tile * 32 + threadIdx.x;
-        if (node < C) { my_k0 = csc_split[node]; my_len = cscptr[node + 1] - my_k0; }
+    int k0, len, node, kb = -1;
+    if (tiles) {                                   // the tile's nodes ranked by list length, laid down by the plan
+        const int4 ti = tiles[map.tile * 32 + (threadIdx.x >> 3)];
+        k0 = ti.x; len = ti.y; node = ti.z; kb = ti.w;
+    } else {
+        int my_k0 = 0, my_len = 0;
+        if (threadIdx.x < 32) {
+            const int n = map.tile * 32 + threadIdx.x;
+            if (n < C) { my_k0 = csc_split[n]; my_len = cscptr[n + 1] - my_k0; }
+        }
+        node = map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
     }
-    int k0, len;
-    const int node = map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (wpart) {
         const f32x4 aseg = *reinterpret_cast<const f32x4*>(act + (int64_t)min(node, C - 1) * ldb + col0 + s4);
-        ov_gather_grp_wgrad(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz);
+        ov_gather_grp_wgrad(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz, kb);
     } else {
         ov_gather_grp<true, OV_GENE_BWD_U>(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane);
     }
@@ -2368,7 +2379,7 @@ static int ov_launch_gemm(const OvGemm& g, int S, bool vec, hipStream_t st) {
     const int bm = KW == 1 ? 64 * MT : 32 * MT, bn = KW == 1 ? 64 * NT : 32 * NT;
     dim3 grid((g.N + bn - 1) / bn, (g.M + bm - 1) / bm, S);
     size_t lds = 0;
-    if (KW == 4) lds = (size_t)4 * MT * NT * 16 * 64 * sizeof(float);
+    if (KW == 4) lds = (size_t)4 * 16 * 64 * sizeof(float);
     if (!B_KC && g.bgather) lds = std::max(lds, (size_t)std::min(g.K, g.kchunk) * sizeof(int32_t));
     if (EPI == OV_EPI_ADAMW_T) {
         if (KW != 1) { ontovae_set_error("gemm: the transposed AdamW epilogue needs KW == 1"); return ONTOVAE_EINVAL; }
@@ -2831,7 +2842,10 @@ static int ov_dec_gene(OvStep& s, float* rec_out, int64_t rec_ld) {
         const int ncb = s.ldb / 32, ntiles = (d.G + 31) / 32;
         hipLaunchKernelGGL((ov_gene_cb_kernel<MODE>), dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->rowptr, c->colidx, vals, bias,
                            s.ws.act, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C, ncb, ntiles,
-                           MODE == 1 ? s.gw_bpart : (float*)nullptr, s.gw_rows, s.gw_row0);
+                           MODE == 1 ? s.gw_bpart : (float*)nullptr, s.gw_rows, s.gw_row0,
+                           // the plan's tile records up to 512 columns (21.2 against 22.9 us at 128); beyond, where every XCD works
+                           // through many column blocks, the kernel is 3 to 8 % faster when its workgroups rank their rows themselves
+                           s.ldb < 1024 ? reinterpret_cast<const int4*>(c->gene_tiles) : (const int4*)nullptr);
         OV_LAUNCH_CHECK();
         return ONTOVAE_OK;
     }
@@ -2899,7 +2913,8 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
         // (1024 columns: 170 us with 4 against 176 with 5; 8192: 1.40 ms with 3, 1.43 with 4, 1.52 with 5)
         const int wpe = s.ldb >= 4096 ? 3 : (s.ldb >= 1024 ? 4 : 5);
 #define OV_BG_CB(W) hipLaunchKernelGGL(ov_bwd_gene_cb_kernel<W>, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row, \
-                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles, s.ws.act, s.gw_part, (int64_t)d.nnz, 0)
+                           c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles, s.ws.act, s.gw_part, (int64_t)d.nnz, \
+                           reinterpret_cast<const int4*>(c->panel_tiles))
         if (wpe == 3) OV_BG_CB(3); else if (wpe == 4) OV_BG_CB(4); else OV_BG_CB(5);
 #undef OV_BG_CB
         OV_LAUNCH_CHECK();

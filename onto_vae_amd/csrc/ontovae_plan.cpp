@@ -50,7 +50,48 @@ struct ontovae_plan {
         std::vector<int32_t> gene, quad0, k;
         std::vector<uint16_t> col;
     } gsell;
+    // tiles of 32 rows as the column-block gene kernels take them (ontovae_plan_tile_info), 4 ints per slot
+    std::vector<int32_t> gene_tiles, panel_tiles;
 };
+
+// The column-block gene kernels give every lane group of a 32-row tile one row, longest list first, so that the 8 groups
+// of a wave walk lists of similar length.  The order is a property of the masks: it is laid down here once, one 16-B record
+// per slot {first list position, length, row, packed position of the first link}, instead of being found by every workgroup
+// (row pointers -> LDS -> rank by counting -> LDS, two barriers) before its first useful load.
+//   gene tiles : rows = genes g (record.z = g, G for an unused slot), lists = CSR rows C + g, record.w = 0
+//   panel tiles: rows = panel nodes p (record.z = p, C if unused), lists = gene part of CSC column p
+static void build_tiles(ontovae_plan* p) {
+    const int32_t C = p->dims.C, G = (int32_t)(p->rowptr.size() - 1) - C;
+    auto make = [&](int32_t n, int32_t unused, auto k0_of, auto len_of, auto kb_of, std::vector<int32_t>& out) {
+        const int32_t ntiles = (n + 31) / 32;
+        out.assign((size_t)ntiles * 32 * 4, 0);
+        for (int32_t t = 0; t < ntiles; ++t) {
+            std::vector<std::pair<int32_t, int32_t>> v;     // (len, row); rows beyond n: length 0
+            for (int32_t j = 0; j < 32; ++j) {
+                const int32_t r = t * 32 + j;
+                v.push_back({r < n ? len_of(r) : 0, r});
+            }
+            std::stable_sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+            for (int32_t s = 0; s < 32; ++s) {
+                const int32_t r = v[s].second;
+                int32_t* rec = out.data() + ((size_t)t * 32 + s) * 4;
+                rec[0] = r < n ? k0_of(r) : 0;
+                rec[1] = v[s].first;
+                rec[2] = r < n ? r : unused;
+                rec[3] = (r < n && v[s].first > 0) ? kb_of(r) : 0;
+            }
+        }
+    };
+    make(G, G, [&](int32_t g) { return p->rowptr[C + g]; }, [&](int32_t g) { return p->rowptr[C + g + 1] - p->rowptr[C + g]; },
+         [&](int32_t) { return 0; }, p->gene_tiles);
+    auto split = [&](int32_t c) {
+        const int32_t* b = p->csc_row.data() + p->cscptr[c];
+        const int32_t* e = p->csc_row.data() + p->cscptr[c + 1];
+        return (int32_t)(std::lower_bound(b, e, C) - p->csc_row.data());
+    };
+    make(C, C, split, [&](int32_t c) { return p->cscptr[c + 1] - split(c); }, [&](int32_t c) { return p->csc_k[split(c)]; },
+         p->panel_tiles);
+}
 
 // Gene layer, one gene per lane.  List lengths run from 3 to 60 links at GO-BP scale: slices of 64 consecutive genes would be
 // 1.85x padding, slices of genes sorted inside windows of 512 are 1.15x (entries in quads of 4), and a wave's genes stay
@@ -352,6 +393,7 @@ static int build(int32_t K, const int32_t* rows, const int32_t* cols, int32_t nu
     build_sell(p, 0);
     build_sell(p, 1);
     build_gsell(p);
+    build_tiles(p);
     p->dims.G = (int32_t)G;
     p->dims.T = (int32_t)T;
     p->dims.K = K;
@@ -480,6 +522,13 @@ extern "C" int ontovae_plan_gsell_export(const ontovae_plan_t* plan, int32_t* ge
     if (quad0) std::memcpy(quad0, S.quad0.data(), sizeof(int32_t) * S.quad0.size());
     if (col && !S.col.empty()) std::memcpy(col, S.col.data(), sizeof(uint16_t) * S.col.size());
     if (k && !S.k.empty()) std::memcpy(k, S.k.data(), sizeof(int32_t) * S.k.size());
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_plan_tile_info(const ontovae_plan_t* plan, int32_t which, int32_t* out) {
+    if (!plan || !out || which < 0 || which > 1) return ONTOVAE_EINVAL;
+    const std::vector<int32_t>& v = which == 0 ? plan->gene_tiles : plan->panel_tiles;
+    if (!v.empty()) std::memcpy(out, v.data(), sizeof(int32_t) * v.size());
     return ONTOVAE_OK;
 }
 

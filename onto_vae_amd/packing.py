@@ -78,6 +78,11 @@ class MaskPlan:
         _lib.check(L.ontovae_plan_gsell_export(handle, _i32p(self.gsell["gene"]), _i32p(self.gsell["quad0"]),
                                                self.gsell["col"].ctypes.data_as(C.POINTER(C.c_uint16)), _i32p(self.gsell["k"])),
                    "gsell export")
+        # 32-row tiles of the column-block gene kernels, rows ranked by list length (ontovae_plan_tile_info)
+        self.gene_tiles = np.zeros((self.G + 31) // 32 * 32 * 4, dtype=np.int32)
+        self.panel_tiles = np.zeros(max((self.C + 31) // 32 * 32 * 4, 4), dtype=np.int32)
+        _lib.check(L.ontovae_plan_tile_info(handle, 0, _i32p(self.gene_tiles)), "gene tiles")
+        _lib.check(L.ontovae_plan_tile_info(handle, 1, _i32p(self.panel_tiles)), "panel tiles")
         self.entry_layer = np.zeros(n, dtype=np.int32)
         self.entry_row = np.zeros(n, dtype=np.int32)
         self.entry_col = np.zeros(n, dtype=np.int32)

@@ -84,6 +84,25 @@ def check_plan(masks, nu):
             prev_len[w] = lens[-1]
     else:
         assert gs["n_slices"] == 0
+    # 32-row tiles of the column-block gene kernels: every row of a tile once, longest list first, with its list
+    gt = plan.gene_tiles.reshape(-1, 32, 4)
+    pt = plan.panel_tiles.reshape(-1, 32, 4)
+    assert gt.shape[0] == (plan.G + 31) // 32 and pt.shape[0] == (C + 31) // 32
+    for tiles, n, unused in ((gt, plan.G, plan.G), (pt, C, C)):
+        for t, rec in enumerate(tiles):
+            rows_ = rec[:, 2]
+            want_rows = [r for r in range(t * 32, t * 32 + 32) if r < n]
+            assert sorted(rows_[rows_ != unused].tolist()) == want_rows
+            assert np.all(np.diff(rec[:, 1]) <= 0) and np.all(rec[rows_ == unused, 1] == 0)
+    for rec in gt.reshape(-1, 4):
+        if rec[2] < plan.G:
+            assert rec[0] == plan.rowptr[C + rec[2]] and rec[1] == plan.rowptr[C + rec[2] + 1] - rec[0]
+    for rec in pt.reshape(-1, 4):
+        if rec[2] < C:
+            p_ = rec[2]
+            assert rec[0] == plan.csc_split[p_] and rec[1] == plan.cscptr[p_ + 1] - plan.csc_split[p_]
+            if rec[1] > 0:
+                assert rec[3] == plan.csc_k[rec[0]]
     # levels tile the panel in reverse order and then the genes
     assert plan.level_begin[0] == C - plan.L and plan.level_end[0] == C
     for d in range(1, plan.K):
