@@ -1747,17 +1747,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
 // Backward data, one wave per (panel node of the level, batch chunk), CSC gather:
 //   D[p, :] = sum_q vals[csc_k[q]] * D[csc_row[q], :]
+// csc_split != NULL: the term part of the lists only, added to what D[p, :] holds (the gene part, from ov_bwd_gene_cb_kernel)
 template <int VEC>
 __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_row,
                                                         const int32_t* __restrict__ csc_k, const float* __restrict__ vals,
-                                                        float* __restrict__ d, int node_begin, int node_end, int ldb) {
+                                                        float* __restrict__ d, int node_begin, int node_end, int ldb,
+                                                        const int32_t* __restrict__ csc_split) {
     const int node = node_begin + blockIdx.x * 4 + ov_wave_id();
     if (node >= node_end) return;
     const int b0 = blockIdx.y * (64 * VEC) + ov_lane() * VEC;
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    const int q0 = cscptr[node], q1 = cscptr[node + 1];
+    const int q0 = cscptr[node], q1 = csc_split ? csc_split[node] : cscptr[node + 1];
+    if (csc_split) {
+        if (q1 == q0) return;                      // no term children: the row is final
+        ov_ldv<VEC>(d + (int64_t)node * ldb + b0, acc);
+    }
     int q = q0;
     for (; q + 4 <= q1; q += 4) {
         float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
@@ -2874,13 +2880,14 @@ static int ov_nrec(const OvStep& s) {
     return (tiled ? (d.G + OV_GT_GENES - 1) / OV_GT_GENES : (d.G + 3) / 4) * s.nchunk;
 }
 
-static int ov_dec_bwd_level(OvStep& s, int nb, int ne) {
+static int ov_dec_bwd_level(OvStep& s, int nb, int ne, bool term_part_only = false) {
     const ontovae_ctx_t* c = s.c;
     if (ne <= nb) return ONTOVAE_OK;
     dim3 grid((ne - nb + 3) / 4, s.nchunk);
     const float* vals = c->P + c->lay.dec_vals;
     OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
-#define OV_DB(V) hipLaunchKernelGGL((ov_dec_bwd_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_row, c->csc_k, vals, s.ws.d, nb, ne, s.ldb)
+#define OV_DB(V) hipLaunchKernelGGL((ov_dec_bwd_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_row, c->csc_k, vals, s.ws.d, nb, ne, s.ldb, \
+                                    term_part_only ? c->csc_split : (const int32_t*)nullptr)
     if (s.vec == 1) OV_DB(1); else if (s.vec == 2) OV_DB(2); else OV_DB(4);
 #undef OV_DB
     OV_LAUNCH_CHECK();
@@ -2904,10 +2911,15 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
     }
     const float* vals = c->P + c->lay.dec_vals;
     float* blk = nullptr;
+    // as in the forward pass: from OV_CHAIN_MAX_LDB columns on, one launch per level over the whole batch instead of the LDS
+    // chain (a workgroup of the chain carries 4 columns: many rounds of latency-bound workgroups), and the gene backward
+    // then has no column-group-major copy of D to write
+    // (8192 columns: gene backward 1.37 -> 1.27 ms, term part 270 -> 204 us; 2048: 349 + 65 -> 320 + 85 us)
+    const bool per_level = s.ldb >= OV_CHAIN_MAX_LDB && !fin;
     if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
         const int ncb = s.ldb / 32, ntiles = (d.C + 31) / 32;
-        if (bt == 4) blk = s.ws.dblk;           // the chain's workgroups take 4 columns each: hand them contiguous pieces
+        if (bt == 4 && !per_level) blk = s.ws.dblk;           // the chain's workgroups take 4 columns each: hand them contiguous pieces
         // waves per SIMD: the kernel needs 5 to cover its latencies while 4 column blocks are all there is (22.1 us at 128
         // columns against 24.7 with 4); once every XCD works through many blocks, fewer waves leave more of its L2 to each
         // (1024 columns: 170 us with 4 against 176 with 5; 8192: 1.40 ms with 3, 1.43 with 4, 1.52 with 5)
@@ -2925,6 +2937,11 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
         if (s.vec == 1) OV_BG(1); else if (s.vec == 2) OV_BG(2); else OV_BG(4);
 #undef OV_BG
         OV_LAUNCH_CHECK();
+    }
+    if (per_level) {
+        for (int lvl = d.K - 1; lvl >= 0; --lvl)
+            if ((rc = ov_dec_bwd_level(s, c->level_begin[lvl], c->level_end[lvl], true))) return rc;
+        return ONTOVAE_OK;
     }
     const ontovae_sell_t& sb = c->sell_bwd;
     OvSteps lv;
