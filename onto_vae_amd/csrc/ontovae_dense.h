@@ -434,7 +434,8 @@ extern "C" int ontovae_vae_train_step(const ontovae_vae_ctx_t* ctx, const float*
                         ctx->P + n.bh, ctx->M ? ctx->M + n.bh : nullptr, ctx->V ? ctx->V + n.bh : nullptr, ctx->Gr ? ctx->Gr + n.bh : nullptr,
                         s.apply, s.adam, OvLossArgs{s.ws.rec_part, nrec, s.ws.kl_part, nkl, kl_coeff, loss_out}, n.Z + 1};
         OvWgradArgs none{};
-        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(la.nblocks), dim3(256), 0, s.st, la, none, 0);
+        OvFinishArgs nofin{};
+        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(la.nblocks), dim3(256), 0, s.st, la, none, 0, nofin, 0);
         OV_LAUNCH_CHECK();
     }
     // heads: da = Wh^T dmulv (before Wh moves), dWh = dmulv a^T

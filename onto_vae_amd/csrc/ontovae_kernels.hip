@@ -1978,10 +1978,19 @@ __global__ __launch_bounds__(1024) void ov_chain_bwd_finish_kernel(const OvChain
 // costs no launch of its own (all parts are 256-thread workgroups):
 //   latent backward (a few dozen workgroups)  +  weight-gradient partials of the rows the backward chain finished
 //   da = Wh^T dmulv (split-K GEMM)             +  the finish pass over the partials (AdamW + clamp)
-__global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const OvLatentArgs la, const OvWgradArgs wa, int wteams) {
+// fblocks > 0 (large batches): workgroups [nblocks, nblocks + fblocks) run the finish pass of the gene layer's update.  Its
+// partials are final since the gene backward kernel and nothing reads those weights again in the step; it is a pure HBM
+// stream (0.5 GB at 8192 rows), and the weight-gradient workgroups that share this launch are many, short and bound by their
+// memory round trips.  They come first in the id order, so that they are resident while the others pass through.
+__global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const OvLatentArgs la, const OvWgradArgs wa, int wteams, const OvFinishArgs fa,
+                                                           int fblocks) {
     __shared__ int sh_k0[32], sh_len[32], sh_ord[32];
-    if ((int)blockIdx.x < la.nblocks) { ov_latent_bwd_body(la, blockIdx.x); return; }
-    if ((int)blockIdx.x - la.nblocks < wteams) ov_wgrad_cb_body(wa, (int)blockIdx.x - la.nblocks, threadIdx.x, sh_k0, sh_len, sh_ord);
+    int b = blockIdx.x;
+    if (b < la.nblocks) { ov_latent_bwd_body(la, b); return; }
+    b -= la.nblocks;
+    if (b < fblocks) { ov_wgrad_finish_body(fa, (int64_t)b * 256 + threadIdx.x, (int64_t)fblocks * 256); return; }
+    b -= fblocks;
+    if (b < wteams) ov_wgrad_cb_body(wa, b, threadIdx.x, sh_k0, sh_len, sh_ord);
 }
 template <bool VEC>
 __global__ __launch_bounds__(256) void ov_da_gemm_kernel(const OvGemm g, int gx, int gy, int gz, const OvFinishArgs fa, int fblocks) {
@@ -3294,7 +3303,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     OvWgradArgs wt = wa;
     OvFinishArgs fa{}, fa_gene{};
     int wteams = 0, fblocks = 0, gblocks = 0;
-    bool ride_fin = false;
+    bool ride_fin = false, ride_lat = false;
     const bool riders2 = wcb && !s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS);
     if (wcb) {
         wt.row0 = 0;
@@ -3311,11 +3320,15 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         // only while the chain leaves most of the chip idle (<= 128 workgroups): at larger batches the chain's workgroups
         // fill every CU themselves and 1024-thread riders next to their LDS reservation only stretch the launch
         ride_fin = fused_gw && s.ldb / std::max(ov_fused_bt(c), 1) <= 128;
-        if (ride_fin) {
+        // large batches: the gene layer's finish pass (a stream over ldb / 32 copies of the gene layer's links) rides with the
+        // latent backward and the term rows' partials instead of stretching the da launch
+        ride_lat = fused_gw && !ride_fin && riders2 && s.ldb >= 512;
+        if (ride_fin || ride_lat) {
             fa_gene = fa;
             fa_gene.sel = 1;
             fa.sel = 2;
-            gblocks = (int)std::min<int64_t>(((int64_t)d.nnz + 1023) / 1024, 448);      // 1024-thread workgroups beside the chain
+            gblocks = ride_fin ? (int)std::min<int64_t>(((int64_t)d.nnz + 1023) / 1024, 448)       // 1024-thread workgroups beside the chain
+                               : (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 512);        // 256-thread ones, two per CU
             fblocks = (int)std::min<int64_t>(((int64_t)d.nnz_term + d.C + 255) / 256, 2048);
         }
     }
@@ -3346,8 +3359,9 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                         c->Gr ? c->Gr + lay.bh : nullptr, apply, adam,
                         OvLossArgs{s.ws.rec_part, ov_nrec(s), s.ws.kl_part, nkl, kc, loss_out}, d.L + 1};
         OvProfScope prof(ONTOVAE_PHASE_LATENT_BWD, s.st);
-        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(la.nblocks + (riders2 ? wteams : 0)), dim3(256), 0, s.st, la, wt,
-                           riders2 ? wteams : 0);
+        const int lfin = ride_lat ? gblocks : 0;
+        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(la.nblocks + lfin + (riders2 ? wteams : 0)), dim3(256), 0, s.st, la, wt,
+                           riders2 ? wteams : 0, fa_gene, lfin);
         OV_LAUNCH_CHECK();
     }
     // da = Wh^T dmulv  (before Wh is updated) [+ finish pass of the decoder weight update]
