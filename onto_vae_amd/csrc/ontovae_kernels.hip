@@ -118,6 +118,7 @@ struct OvWs {
     float *rec_part, *kl_part;
     float *wpart;              // [ldb / 32][nnz + C + G] weight-gradient partials of the 32-column blocks
     float *wgene;              // [nnz - nnz_term] gene-layer weights in CSR order, refreshed from P at the start of every pass
+    float *whT;                // [L][2 L] transposed copy of the head weights (da at large batches)
     float *gb4;                // [ldb / 4][lanes of the gene layer's SELL form] gene bias gradient partials of ov_gene_lds_kernel
     int64_t slab_floats;
     int npart_max;
@@ -182,6 +183,7 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, int train_batch,
     w.wpart = take((tldb / 32) * ((int64_t)d.nnz + C + G));
     w.wgene = take((int64_t)d.nnz - d.nnz_term);
     w.gb4 = take((tldb / 4) * ov_gsell_lanes_max(d.G));
+    w.whT = take(2 * L * L);
     w.slab_floats = slab;
     w.npart_max = (int)npart;
     if (ws) *ws = w;
@@ -1947,11 +1949,35 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
         }
     }
     const int rb = terms ? 0 : a.n_term_rows, re = (genes && !a.gb4) ? a.nrows : a.n_term_rows;
+    auto node_of_row = [&](int64_t r) { return r < a.n_term_rows ? a.first_term_node + (int)r : a.C + ((int)r - a.n_term_rows); };
+    if (a.ncb >= 16) {
+        // many column blocks: 16 rows per wave, the blocks in 4 runs of eight loads in flight, run sums added in run order
+        // (the term layers' 8640 rows alone were 118 us at 8192 batch rows as one thread per row, 256 loads one behind the other)
+        const int ii = (int)(first & 15), seg = (int)((first >> 4) & 3);
+        const int per = (a.ncb + 3) / 4, c0 = seg * per, c1 = min(c0 + per, a.ncb);
+        for (int64_t r0 = rb + (first >> 6) * 16; r0 < re; r0 += (stride >> 6) * 16) {        // wave-uniform trip count
+            const int64_t r = r0 + ii;
+            float g = 0.f;
+            if (r < re) {
+                int cb = c0;
+                for (; cb + 8 <= c1; cb += 8) {
+                    float t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = a.bpart[(int64_t)(cb + j) * a.nrows + r];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g += t[j];
+                }
+                for (; cb < c1; ++cb) g += a.bpart[(int64_t)cb * a.nrows + r];
+            }
+            const float g1 = __shfl(g, ii + 16, 64), g2 = __shfl(g, ii + 32, 64), g3 = __shfl(g, ii + 48, 64);
+            if (seg == 0 && r < re) update_bias(node_of_row(r), ((g + g1) + g2) + g3);
+        }
+        return;
+    }
     for (int64_t r = rb + first; r < re; r += stride) {
         float g = 0.f;
         for (int cb = 0; cb < a.ncb; ++cb) g += a.bpart[(int64_t)cb * a.nrows + r];
-        const int node = r < a.n_term_rows ? a.first_term_node + (int)r : a.C + ((int)r - a.n_term_rows);
-        update_bias(node, g);
+        update_bias(node_of_row(r), g);
     }
 }
 __global__ __launch_bounds__(256) void ov_wgrad_finish_kernel(const OvFinishArgs a) {
@@ -1991,6 +2017,29 @@ __global__ __launch_bounds__(256) void ov_latent_bwd_kernel(const OvLatentArgs l
     if (b < fblocks) { ov_wgrad_finish_body(fa, (int64_t)b * 256 + threadIdx.x, (int64_t)fblocks * 256); return; }
     b -= fblocks;
     if (b < wteams) ov_wgrad_cb_body(wa, b, threadIdx.x, sh_k0, sh_len, sh_ord);
+}
+// Large batches: da = Wh^T dmulv goes through the LDS-staged GEMM, which wants its A operand with k contiguous.  One small
+// launch makes the transposed copy of Wh ([2 L, L] -> [L, 2 L], 32 x 32 tiles) and carries the finish pass that would
+// otherwise ride with the da GEMM.
+__global__ __launch_bounds__(256) void ov_whT_finish_kernel(const float* __restrict__ src, int R, int F, float* __restrict__ dst,
+                                                           int ntx, int nty, const OvFinishArgs fa, int fblocks) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.x;
+    if (b < ntx * nty) {
+        const int f0 = (b % ntx) * 32, r0 = (b / ntx) * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int j = ty; j < 32; j += 8) {
+            const int r = r0 + j, f = f0 + tx;
+            tile[j][tx] = (f < F && r < R) ? src[(int64_t)r * F + f] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int f = f0 + j, r = r0 + tx;
+            if (f < F && r < R) dst[(int64_t)f * R + r] = tile[tx][j];
+        }
+        return;
+    }
+    ov_wgrad_finish_body(fa, (int64_t)(b - ntx * nty) * 256 + threadIdx.x, (int64_t)fblocks * 256);
 }
 template <bool VEC>
 __global__ __launch_bounds__(256) void ov_da_gemm_kernel(const OvGemm g, int gx, int gy, int gz, const OvFinishArgs fa, int fblocks) {
@@ -3373,16 +3422,29 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         g.B = s.ws.dmulv; g.ldb = s.ldb;
         // split-K partials into the (free) encoder slab buffer; the BatchNorm backward adds them
         const int64_t one = (int64_t)d.L * s.ldb;
-        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(4, s.ws.slab_floats / one));
+        // from 2048 columns on: 96 x 128 tiles staged through LDS (the 32 x 32 split-K tiles reach 21 TFLOP/s at 8192 columns, this
+        // kernel 70; at 1024 columns the two are equal once the copy's launch is counted)
+        const bool da_lds = s.ldb >= 2048 && (d.L % 4 == 0) && ov_al16(g.B) && ov_al16(s.ws.whT);
+        const int tiles_lds = ((d.L + 95) / 96) * ((s.B + 127) / 128);
+        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(da_lds ? std::min(4, 256 / std::max(tiles_lds, 1)) : 4, s.ws.slab_floats / one));
         const int kchunk = ((2 * d.L + S - 1) / S + 31) / 32 * 32;
         da_S = (2 * d.L + kchunk - 1) / kchunk;
         g.C = da_S > 1 ? s.ws.slab : s.ws.da; g.ldc = s.ldb; g.slab_stride = one; g.kchunk = kchunk;
         OvProfScope prof(ONTOVAE_PHASE_DA_GEMM, s.st);
+        if (da_lds) {
+            const int ntx = (d.L + 31) / 32, nty = (2 * d.L + 31) / 32;
+            hipLaunchKernelGGL(ov_whT_finish_kernel, dim3(ntx * nty + (riders2 ? fblocks : 0)), dim3(256), 0, s.st, c->P + lay.Wh, 2 * d.L, d.L,
+                               s.ws.whT, ntx, nty, fa, riders2 ? fblocks : 0);
+            OV_LAUNCH_CHECK();
+            g.A = s.ws.whT; g.lda = 2 * d.L;          // A(m=l, k=j) = WhT[l * 2L + j]
+            if ((rc = ov_launch_gemm_lds<1, 4, false, OV_EPI_STORE>(g, da_S, s.st))) return rc;
+        } else {
         const int gx = (g.N + 31) / 32, gy = (g.M + 31) / 32;
         const size_t lds = (size_t)4 * 16 * 64 * sizeof(float);        // KW == 4 reduction area of a 1 x 1 tile
         hipLaunchKernelGGL((ov_da_gemm_kernel<false>), dim3(gx * gy * da_S + (riders2 ? fblocks : 0)), dim3(256), lds, s.st, g, gx, gy,
                            da_S, fa, riders2 ? fblocks : 0);
         OV_LAUNCH_CHECK();
+        }
     }
     // dWh = dmulv a^T (+ AdamW) and the BatchNorm backward (dh; AdamW of gamma, beta, b0): independent, one launch on
     // the single-stream path.  (dbh is done by the latent backward launch.)
