@@ -164,8 +164,10 @@ int ontovae_plan_gsell_export(const ontovae_plan_t* plan, int32_t* gene, int32_t
 /* Tiles of 32 rows as the column-block gene kernels take them: for every tile the 32 rows in order of decreasing list length,
  * one record of 4 ints per slot {first list position, list length, row, packed position of the list's first link}.
  * which = 0: gene tiles ([ceil(G / 32) * 32 * 4]; rows are genes, lists the CSR rows of the gene layer, unused slots have row G);
- * which = 1: panel tiles ([ceil(C / 32) * 32 * 4]; rows are panel nodes, lists the gene part of their CSC columns, unused: row C).
- * Optional in the context (NULL: every workgroup ranks its tile's rows itself, as before ABI 6). */
+ * which = 1: panel tiles ([ceil(C / 32) * 32 * 4]; rows are panel nodes, lists the gene part of their CSC columns, unused: row C);
+ * which = 2: term tiles ([ceil((C - L) / 32) * 32 * 4]; rows are the term layers' output nodes [0, C - L), lists their CSR rows,
+ *            unused: row C - L): what the weight-gradient workgroups of the term layers read first.
+ * Optional in the context (NULL: every workgroup ranks its tile's rows itself). */
 int ontovae_plan_tile_info(const ontovae_plan_t* plan, int32_t which, int32_t* out);
 
 typedef struct ontovae_layout {
@@ -223,6 +225,7 @@ typedef struct ontovae_ctx {
     ontovae_gsell_t gsell;     /* n_slices == 0: not provided */
     const int32_t* gene_tiles; /* device, ontovae_plan_tile_info(plan, 0), or NULL */
     const int32_t* panel_tiles;/* device, ontovae_plan_tile_info(plan, 1), or NULL */
+    const int32_t* term_tiles; /* device, ontovae_plan_tile_info(plan, 2), or NULL */
 } ontovae_ctx_t;
 
 #define ONTOVAE_FLAG_LEVEL_LAUNCHES 1u  /* one launch per decoder level instead of the LDS-fused chain */

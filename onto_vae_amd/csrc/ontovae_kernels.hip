@@ -1806,6 +1806,7 @@ struct OvWgradArgs {
     int64_t nnz;
     int row0, nrows_part, nrows;      // this launch covers rows [row0, row0 + nrows_part) of the nrows rows
     int first_term_node, n_term_rows, C, ldb, ncb, ntiles;
+    const int4* tiles;                // the plan's records of the term tiles (launches that cover exactly the term rows), or NULL
 };
 // wg: virtual workgroup number of the 256-thread team, tid: thread number inside the team.  Every thread of the
 // real workgroup must call this (one workgroup barrier pair inside).
@@ -1817,14 +1818,20 @@ __device__ __forceinline__ void ov_wgrad_cb_body(const OvWgradArgs& a, int wg, i
     const int col0 = map.cb * 32, s4 = 4 * s;
     auto node_of = [&](int r) { return r < a.n_term_rows ? a.first_term_node + r : a.C + (r - a.n_term_rows); };
     const int rend = a.row0 + a.nrows_part;
-    int my_k0 = 0, my_len = 0;
-    if (tile_on && tid < 32) {
-        const int r = a.row0 + map.tile * 32 + tid;
-        if (r < rend) { const int n = node_of(r); my_k0 = a.rowptr[n]; my_len = a.rowptr[n + 1] - my_k0; }
+    int k0, len, r;
+    if (a.tiles) {                                   // the tile's rows ranked by list length, laid down by the plan
+        if (!tile_on) return;
+        const int4 ti = a.tiles[map.tile * 32 + (tid >> 3)];
+        k0 = ti.x; len = ti.y; r = ti.z;             // an unused slot has r = n_term_rows = rend
+    } else {
+        int my_k0 = 0, my_len = 0;
+        if (tile_on && tid < 32) {
+            const int rr = a.row0 + map.tile * 32 + tid;
+            if (rr < rend) { const int n = node_of(rr); my_k0 = a.rowptr[n]; my_len = a.rowptr[n + 1] - my_k0; }
+        }
+        r = a.row0 + map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len, tid);
+        if (!tile_on) return;                        // no barrier below
     }
-    int k0, len;
-    const int r = a.row0 + map.tile * 32 + ov_tile_balance(my_k0, my_len, sh_k0, sh_len, sh_ord, k0, len, tid);
-    if (!tile_on) return;                            // no barrier below
     const bool row_on = r < rend;
     const int node = node_of(min(r, rend - 1));
     const f32x4 dseg = *reinterpret_cast<const f32x4*>(a.d + (int64_t)node * a.ldb + col0 + s4);
@@ -3358,6 +3365,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         wt.row0 = 0;
         wt.nrows_part = fused_gw ? wrows - ride_rows : wrows;
         wt.ntiles = (wt.nrows_part + 31) / 32;
+        wt.tiles = (wt.nrows_part == n_term_rows && wt.first_term_node == 0) ? reinterpret_cast<const int4*>(c->term_tiles) : nullptr;
         wteams = ov_cb_grid(wt.ncb, wt.ntiles);
         fblocks = (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 2048);
         fa = OvFinishArgs{wa.part, wa.bpart, wa.ncb, (int64_t)d.nnz, wrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,

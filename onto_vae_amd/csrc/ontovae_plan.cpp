@@ -51,7 +51,7 @@ struct ontovae_plan {
         std::vector<uint16_t> col;
     } gsell;
     // tiles of 32 rows as the column-block gene kernels take them (ontovae_plan_tile_info), 4 ints per slot
-    std::vector<int32_t> gene_tiles, panel_tiles;
+    std::vector<int32_t> gene_tiles, panel_tiles, term_tiles;
 };
 
 // The column-block gene kernels give every lane group of a 32-row tile one row, longest list first, so that the 8 groups
@@ -60,6 +60,7 @@ struct ontovae_plan {
 // (row pointers -> LDS -> rank by counting -> LDS, two barriers) before its first useful load.
 //   gene tiles : rows = genes g (record.z = g, G for an unused slot), lists = CSR rows C + g, record.w = 0
 //   panel tiles: rows = panel nodes p (record.z = p, C if unused), lists = gene part of CSC column p
+//   term tiles : rows = the term layers' output nodes n in [0, C - L) (record.z = n, C - L if unused), lists = CSR rows n
 static void build_tiles(ontovae_plan* p) {
     const int32_t C = p->dims.C, G = (int32_t)(p->rowptr.size() - 1) - C;
     auto make = [&](int32_t n, int32_t unused, auto k0_of, auto len_of, auto kb_of, std::vector<int32_t>& out) {
@@ -91,6 +92,9 @@ static void build_tiles(ontovae_plan* p) {
     };
     make(C, C, split, [&](int32_t c) { return p->cscptr[c + 1] - split(c); }, [&](int32_t c) { return p->csc_k[split(c)]; },
          p->panel_tiles);
+    const int32_t nterm = p->level_begin.empty() ? 0 : p->level_begin[0];      // nodes [0, C - L): levels 1 .. K-1
+    make(nterm, nterm, [&](int32_t n) { return p->rowptr[n]; }, [&](int32_t n) { return p->rowptr[n + 1] - p->rowptr[n]; },
+         [&](int32_t) { return 0; }, p->term_tiles);
 }
 
 // Gene layer, one gene per lane.  List lengths run from 3 to 60 links at GO-BP scale: slices of 64 consecutive genes would be
@@ -526,8 +530,8 @@ extern "C" int ontovae_plan_gsell_export(const ontovae_plan_t* plan, int32_t* ge
 }
 
 extern "C" int ontovae_plan_tile_info(const ontovae_plan_t* plan, int32_t which, int32_t* out) {
-    if (!plan || !out || which < 0 || which > 1) return ONTOVAE_EINVAL;
-    const std::vector<int32_t>& v = which == 0 ? plan->gene_tiles : plan->panel_tiles;
+    if (!plan || !out || which < 0 || which > 2) return ONTOVAE_EINVAL;
+    const std::vector<int32_t>& v = which == 0 ? plan->gene_tiles : (which == 1 ? plan->panel_tiles : plan->term_tiles);
     if (!v.empty()) std::memcpy(out, v.data(), sizeof(int32_t) * v.size());
     return ONTOVAE_OK;
 }

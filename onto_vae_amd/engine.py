@@ -164,7 +164,7 @@ class Engine:
         self._gsell["w"] = torch.zeros(max(gs["n_quads"], 1) * 256, dtype=torch.float32, device=dev)
         self._idx = dict(rowptr=t(p.rowptr), colidx=t(p.colidx), cscptr=t(p.cscptr), csc_row=t(p.csc_row),
                          csc_k=t(p.csc_k), csc_split=t(p.csc_split), row_k=t(p.row_k), er=t(p.entry_row), ec=t(p.entry_col),
-                         gene_tiles=t(p.gene_tiles), panel_tiles=t(p.panel_tiles))
+                         gene_tiles=t(p.gene_tiles), panel_tiles=t(p.panel_tiles), term_tiles=t(p.term_tiles))
         self._ctx = None
 
     def to(self, device):
@@ -233,7 +233,7 @@ class Engine:
             c.cscptr, c.csc_row, c.csc_k = _ptr(i["cscptr"]), _ptr(i["csc_row"]), _ptr(i["csc_k"])
             c.csc_split = _ptr(i["csc_split"])
             c.row_k = _ptr(i["row_k"])
-            c.gene_tiles, c.panel_tiles = _ptr(i["gene_tiles"]), _ptr(i["panel_tiles"])
+            c.gene_tiles, c.panel_tiles, c.term_tiles = _ptr(i["gene_tiles"]), _ptr(i["panel_tiles"]), _ptr(i["term_tiles"])
             c.level_begin = self.plan.level_begin.ctypes.data_as(_lib.c_i32p)
             c.level_end = self.plan.level_end.ctypes.data_as(_lib.c_i32p)
             for name, sd, dev in (("sell_fwd", self.plan.sell[0], self._sell[0]), ("sell_bwd", self.plan.sell[1], self._sell[1])):

@@ -83,6 +83,8 @@ class MaskPlan:
         self.panel_tiles = np.zeros(max((self.C + 31) // 32 * 32 * 4, 4), dtype=np.int32)
         _lib.check(L.ontovae_plan_tile_info(handle, 0, _i32p(self.gene_tiles)), "gene tiles")
         _lib.check(L.ontovae_plan_tile_info(handle, 1, _i32p(self.panel_tiles)), "panel tiles")
+        self.term_tiles = np.zeros(max((self.C - self.L + 31) // 32 * 32 * 4, 4), dtype=np.int32)
+        _lib.check(L.ontovae_plan_tile_info(handle, 2, _i32p(self.term_tiles)), "term tiles")
         self.entry_layer = np.zeros(n, dtype=np.int32)
         self.entry_row = np.zeros(n, dtype=np.int32)
         self.entry_col = np.zeros(n, dtype=np.int32)

@@ -88,7 +88,12 @@ def check_plan(masks, nu):
     gt = plan.gene_tiles.reshape(-1, 32, 4)
     pt = plan.panel_tiles.reshape(-1, 32, 4)
     assert gt.shape[0] == (plan.G + 31) // 32 and pt.shape[0] == (C + 31) // 32
-    for tiles, n, unused in ((gt, plan.G, plan.G), (pt, C, C)):
+    nterm = C - plan.L
+    tt = plan.term_tiles[:(nterm + 31) // 32 * 32 * 4].reshape(-1, 32, 4)
+    for rec in tt.reshape(-1, 4):
+        if rec[2] < nterm:
+            assert rec[0] == plan.rowptr[rec[2]] and rec[1] == plan.rowptr[rec[2] + 1] - rec[0]
+    for tiles, n, unused in ((gt, plan.G, plan.G), (pt, C, C), (tt, nterm, nterm)):
         for t, rec in enumerate(tiles):
             rows_ = rec[:, 2]
             want_rows = [r for r in range(t * 32, t * 32 + 32) if r < n]
