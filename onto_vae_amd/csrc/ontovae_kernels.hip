@@ -79,7 +79,7 @@ extern "C" int ontovae_profile_begin(uint32_t phase_mask, int32_t capacity) {
     for (int ph = 0; ph < ONTOVAE_PHASE_COUNT; ++ph) {
         if (!((phase_mask >> ph) & 1u)) continue;
         g_prof.ev[ph] = new hipEvent_t[2 * capacity];
-        for (int i = 0; i < 2 * capacity; ++i) OV_HIP_CHECK(hipEventCreate(&g_prof.ev[ph][i]));
+        for (int i = 0; i < 2 * capacity; ++i) OV_HIP_CHECK(hipEventCreateWithFlags(&g_prof.ev[ph][i], hipEventDisableSystemFence));      // no system-scope release (L2 write-back) charged to the bracketed kernel
     }
     g_prof.mask = phase_mask;
     return ONTOVAE_OK;
