@@ -40,47 +40,91 @@ PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 GLOBAL_BATCH = 8192          # BASELINE.json configs[2]
 
 
-def phase_cost(name, d, B, nnz_t):
-    """Algorithmic (HBM bytes, flops) of the launch(es) of one phase of a training step; None where a phase has no launch of
-    its own.  nnz_t = non-zeros of the term layers, nnz_g of the gene layer; every array is counted once per launch that
-    must read or write it, indices as 4 bytes."""
+PEAK_BF16_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the headline 5 PF figure includes 2:1 sparsity)
+
+
+def step_regime(B, C_=9000):
+    """Which launch carries which rider at batch B (ov_train_tail_a in csrc/ontovae_kernels.hip: fused_gw, ride_fin,
+    ride_lat; ov_ldb): the gene layer's weight gradient is always formed inside its own two kernels (bias partials in the
+    forward one, link partials in the backward one); its FINISH pass (sum of the partials, AdamW, clamp) rides with the
+    backward chain while that launch has <= 128 workgroups, with the latent backward from 512 columns on, and with the
+    da launch in between.  ncb = 32-column blocks of the padded batch; lds = forward gene layer on the LDS-panel kernel."""
+    q = 64 * (1 if B <= 64 else (2 if B <= 128 else 4))
+    ldb = (B + q - 1) // q * q
+    if ldb >= 4096 and ((ldb >> 8) & 1) == 0:
+        ldb += 256
+    lds = 160 * 1024 - 2048
+    bt = 4 if C_ * 16 <= lds else (2 if C_ * 8 <= lds else 1)          # ov_fused_bt: batch columns of the panel a workgroup holds
+    fin = "dec_bwd" if ldb // bt <= 128 else ("latent_bwd" if ldb >= 512 else "da_gemm")
+    return {"ldb": ldb, "ncb": ldb // 32, "gene_finish_in": fin, "lds": ldb >= 512, "levels": ldb >= 2048}
+
+
+def phase_cost(name, d, B, nnz_t, dtype="f32"):
+    """Algorithmic (HBM bytes, flops) of the launch(es) of one phase of a training step at batch B; None where a phase has no
+    launch of its own.  nnz_t = non-zeros of the term layers, nnz_g of the gene layer.  Every array is counted once per
+    launch that must read or write it (the least a launch could move: nothing that an L2 hit or a register could save is
+    charged), indices as 4 bytes, riders charged to the launch that carries them in this batch regime (step_regime)."""
     L, G, C_, nnz = d.L, d.G, d.C, int(d.nnz)
     nnz_g = nnz - nnz_t
+    r = step_regime(B, C_)
+    ncb = r["ncb"]
     f = 4
+    nterm = C_ - L                                                       # term rows of the decoder (their biases too)
+    gb_part = G * (B // 4 if r["lds"] else ncb)                          # gene bias partials: per column group of 4 (LDS kernel) or per block
+    gene_finish = ((nnz_g * ncb + gb_part) + 6 * (nnz_g + G)) * f        # partials in; w, m, v of links and biases in and out
+    gene_finish_fl = 12.0 * (nnz_g + G)
+    term_finish = ((nnz_t + nterm) * ncb + 6 * (nnz_t + nterm)) * f
     cost = {
         "enc_gemm": ((L * G + B * G + L * B) * f, 2.0 * L * G * B),                 # W0, x once, h out
         "bn_fwd": (3 * L * B * f, 10.0 * L * B),                                    # h in, xhat + a out
         "heads": ((2 * L * L + L * B + 2 * L * B) * f, 4.0 * L * L * B),
         "reparam": (6 * L * B * f, 12.0 * L * B),                                   # mu, log_var, eps in; z, eps copy, mu/lv out
-        "dec_fwd_terms": ((2 * nnz_t + L * B + C_ * B) * f, 2.0 * nnz_t * B),       # links, z in, panel out
-        "dec_fwd_gene": ((2 * nnz_g + C_ * B + 2 * G * B) * f, 2.0 * nnz_g * B),    # links, panel in, x in, dL/drecon out
-        "dec_bwd_gene": ((3 * nnz_g + (C_ + G) * B) * f, 2.0 * nnz_g * B),          # links (row, k, w), D genes in, D panel out
-        # backward term chain + (riders) weight-gradient partials of 75 % of the gene rows
-        "dec_bwd": ((2 * nnz_t + 2 * C_ * B + (G + C_) * B + int(0.75 * nnz_g) * (1 + max(B // 32, 1))) * f,
-                    2.0 * nnz_t * B + 1.5 * nnz_g * B),
-        # d mu / d log_var + (riders) partials of the term rows and the other 25 % of the gene rows
-        "latent_bwd": ((6 * L * B + (G + C_) * B // 4 + (nnz_t + nnz_g // 4) * (1 + max(B // 32, 1))) * f,
-                       16.0 * L * B + 2.0 * (nnz_t + 0.25 * nnz_g) * B),
-        # da = Wh^T [dmu; dlv] + (riders) decoder finish pass: partial sums, AdamW on w, m, v, clamp
-        "da_gemm": ((2 * L * L + 3 * L * B + nnz * (max(B // 32, 1) + 6)) * f, 4.0 * L * L * B + 12.0 * nnz),
+        # term levels: links (index + weight), z in, panel out; rider: the forward-ordered copy of the gene weights
+        "dec_fwd_terms": ((2 * nnz_t + L * B + C_ * B + 2 * nnz_g) * f, 2.0 * nnz_t * B),
+        # gene layer + ELBO: links, panel in, x in, dL/drecon out, gene bias partials out
+        "dec_fwd_gene": ((2 * nnz_g + C_ * B + 2 * G * B + gb_part) * f, 2.0 * nnz_g * B),
+        # gene part of the backward + the gene layer's weight-gradient partials: links, D genes in, D panel out, partials out
+        "dec_bwd_gene": ((2 * nnz_g + (C_ + G) * B + nnz_g * ncb) * f, 4.0 * nnz_g * B),
+        # term part of the backward: links, D panel in and out
+        "dec_bwd": ((2 * nnz_t + 2 * C_ * B) * f, 2.0 * nnz_t * B),
+        # d mu / d log_var; rider: weight-gradient partials of the term rows (panel and D rows in, partials out)
+        "latent_bwd": ((6 * L * B + (C_ + nterm) * B + (nnz_t + nterm) * ncb + 2 * nnz_t) * f, 16.0 * L * B + 2.0 * nnz_t * B),
+        # da = Wh^T [dmu; dlv]; rider: finish pass of the term layers
+        "da_gemm": ((2 * L * L + 3 * L * B) * f + term_finish, 4.0 * L * L * B + 12.0 * (nnz_t + nterm)),
         "dwh": ((6 * 2 * L * L + 3 * L * B + 4 * L * B) * f, 4.0 * L * L * B),      # dWh + AdamW, BatchNorm backward
         "dw0": ((6 * L * G + B * G + L * B) * f, 2.0 * L * G * B),                  # w, m, v read + written, x, dh
     }
+    b_, f_ = cost[r["gene_finish_in"]]
+    cost[r["gene_finish_in"]] = (b_ + gene_finish, f_ + gene_finish_fl)
     return cost.get(name)
 
 
-def roofline_entry(name, ms, d, B, nnz_t, traffic):
-    cost = phase_cost(name, d, B, nnz_t)
+MFMA_PHASES = ("enc_gemm", "heads", "da_gemm", "dwh", "dw0")
+BF16_PHASES = ("enc_gemm", "dw0")          # the two products the bf16 variant moves to bf16 MFMA (csrc/ontovae_bf16.h)
+
+
+def roofline_entry(name, ms, d, B, nnz_t, traffic, dtype="f32", overhead_ms=0.0):
+    """One launch (or launch group) against the peak that bounds it.  `ms` is the HIP-event bracket; `us` / `frac` are net of
+    the bracket's own cost (overhead_ms, measured by ontovae_profile_overhead on the same stream), `us_events` / `frac_events`
+    the raw bracket."""
+    cost = phase_cost(name, d, B, nnz_t, dtype)
     if cost is None or ms <= 0:
         return None
     nbytes, flops = cost
-    sec = ms * 1e-3
-    t_hbm, t_mfma = nbytes / (PEAK_HBM_GBS * 1e9), flops / (PEAK_F32_MFMA_TF * 1e12)
-    mfma_kernel = name in ("enc_gemm", "heads", "da_gemm", "dwh", "dw0")
-    bound = "mfma" if (mfma_kernel and t_mfma > t_hbm) else "hbm"
-    e = {"kernel": name, "us": round(ms * 1e3, 2), "bound": bound, "algorithmic_bytes": int(nbytes), "algorithmic_flops": flops,
-         "GBps": round(nbytes / sec / 1e9, 1), "TFLOPs": round(flops / sec / 1e12, 2),
-         "frac": round((t_mfma if bound == "mfma" else t_hbm) / sec, 4), "traffic": traffic.get(name)}
+    peak_tf = PEAK_BF16_MFMA_TF if (dtype == "bf16" and name in BF16_PHASES) else PEAK_F32_MFMA_TF
+    t_hbm, t_mfma = nbytes / (PEAK_HBM_GBS * 1e9), flops / (peak_tf * 1e12)
+    bound = "mfma" if (name in MFMA_PHASES and t_mfma > t_hbm) else "hbm"
+    t_peak = t_mfma if bound == "mfma" else t_hbm
+    sec_raw = ms * 1e-3
+    sec = max(sec_raw - overhead_ms * 1e-3, 0.5 * sec_raw)
+    e = {"kernel": name, "us": round(sec * 1e6, 2), "us_events": round(sec_raw * 1e6, 2), "bound": bound,
+         "algorithmic_bytes": int(nbytes), "algorithmic_flops": flops, "GBps": round(nbytes / sec / 1e9, 1),
+         "TFLOPs": round(flops / sec / 1e12, 2), "peak": peak_tf * 1e3 if bound == "mfma" else PEAK_HBM_GBS,
+         "peak_unit": "GFLOP/s" if bound == "mfma" else "GB/s",
+         "frac": round(t_peak / sec, 4), "frac_events": round(t_peak / sec_raw, 4), "traffic": traffic.get(name)}
+    if e["frac"] > 1.0:
+        e["exceeds_peak"] = True          # the cost model charges this launch more than it can move: a bug in phase_cost
+        print(f"bench.py: roofline fraction {e['frac']} > 1 for {name} at batch {B} ({dtype})", file=sys.stderr)
     return e
 
 
@@ -113,7 +157,10 @@ def synth_X(n, G, device, seed=1234):
 
 
 def cpu_baseline(masks, B, budget_s=20.0):
-    """The dense CPU oracle (same algorithm as the reference) on the host cores: bounded sample."""
+    """The dense CPU oracle (the reference's algorithm: dense masks, dense Linear per depth + concat, dense gradient mask, dense
+    AdamW over all 223 M parameters, dense clamp) on the host cores, BASELINE.md's protocol: 1 warm-up step, median of >= 5
+    steps, the five-phase split, thread count stated.  Bounded sample (~20 s).  numpy (OpenBLAS) rather than torch on purpose:
+    the oracle is the checker of the tests, and it is what is timed."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from ontovae_oracle import OracleOntoVAE
     from onto_vae_amd.synthetic import random_state_dict
@@ -132,27 +179,43 @@ def cpu_baseline(masks, B, budget_s=20.0):
     x = np.log1p(rng.poisson(0.3, size=(B, G))).astype(np.float32)
     eps = rng.standard_normal((B, L)).astype(np.float32)
     o.train_step(x, eps, 1e-4, 1e-4)           # warm-up
-    times = []
+    times, phases = [], []
     t_end = time.time() + budget_s
     while len(times) < 5 or (time.time() < t_end and len(times) < 12):
+        o.phase_seconds = {}
         t0 = time.time()
         o.train_step(x, eps, 1e-4, 1e-4)
         times.append(time.time() - t0)
-        if len(times) >= 3 and time.time() > t_end:
+        phases.append(o.phase_seconds)
+        if len(times) >= 5 and time.time() > t_end:
             break
+    o.phase_seconds = None
     med = float(np.median(times))
+    split = {k: round(float(np.median([p[k] for p in phases])), 4) for k in ("forward", "backward", "grad_mask", "adamw", "clamp")}
     del limiter
-    return {"value": B / med, "unit": "samples/s", "cores": use, "kind": "port",
+    return {"value": B / med, "unit": "samples/s", "cores": use, "host_cpus": cores, "kind": "port",
+            "phase_seconds": split,
             "sample": f"{len(times)} train steps of GOBP-syn at batch {B} after 1 warm-up, median {med:.3f} s/step, "
-                      f"dense numpy oracle (oracle/ontovae_oracle.py) on {use} threads"}
+                      f"dense numpy oracle (oracle/ontovae_oracle.py; numpy/OpenBLAS, not torch) on {use} threads of {cores} host CPUs; "
+                      "phase_seconds = median seconds per step of forward / backward / gradient mask / AdamW / clamp"}
 
 
 def _pmc_traffic():
-    """HBM-side bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), {} if absent."""
+    """HBM-side bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: separate rocprofv3 --pmc runs of
+    profiling/one_step.py, not of this process; `_meta` says on which commit), {} if absent."""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         return {}
+
+
+def event_overhead_ms(dev, n=200):
+    """(null bracket, empty-kernel bracket) in ms: what two events cost by themselves on the launch stream."""
+    from onto_vae_amd import _lib
+    a, b = C.c_float(), C.c_float()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(_lib.lib().ontovae_profile_overhead(st, n, C.byref(a), C.byref(b)), "profile_overhead")
+    return float(a.value), float(b.value)
 
 
 def _timed(fn, steps, world, dev):
@@ -174,19 +237,27 @@ def _timed(fn, steps, world, dev):
     return dt
 
 
-def infer_bench(a, model, dev, world, rank, steps=None, warmup=None):
-    """Inference throughput: every rank streams its own rows (no collective), activities written to a resident
-    [rows, T] output; the kernels are the eval-mode encoder, the term chain and the nu-mean (no gene layer)."""
+INFER_ROWS = 1_000_000       # BASELINE.json configs[3]: get_pathway_activities over 1 M synthetic samples
+
+
+def infer_bench(a, model, dev, world, rank, steps=None, warmup=None, rows=None):
+    """Inference throughput (BASELINE.json configs[3]): every rank streams its own `rows` HBM-resident samples (1 000 000 by
+    default: 80 GB of X generated on the device in chunks, no collective) through ontovae_pass_data in batches, activities
+    written to a resident [rows, T] output; the kernels are the eval-mode encoder, the term levels and the nu-mean (no gene
+    layer).  steps=None: ONE pass over the whole dataset (ceil(rows / batch) batches, the last one partial) is the timed
+    region and a step is one batch; otherwise `steps` batches, cycling."""
     e = model._engine
     d = e.plan.dims
-    steps = a.steps if steps is None else steps
     warmup = a.warmup if warmup is None else warmup
     B = a.batch if a.batch not in (None, 128) else 16384          # 5.56 / 5.73 / 5.84 M samples/s at 4096 / 8192 / 16384 rows per batch
-    rows = max(a.rows // B, 1) * B
+    rows = int(rows if rows is not None else (a.rows if a.rows is not None else INFER_ROWS))
+    rows = max(rows, B)
     model.eval()
     X = synth_X(rows, d.G, dev, seed=1234 + rank)
     out = torch.empty(rows, e.plan.T, dtype=torch.float32, device=dev)
-    nb = rows // B
+    nb = (rows + B - 1) // B
+    whole = steps is None
+    steps = nb if whole else steps
     it = [0]
 
     def step():
@@ -196,24 +267,30 @@ def infer_bench(a, model, dev, world, rank, steps=None, warmup=None):
 
     for _ in range(warmup):
         step()
+    it[0] = 0
     dt = _timed(step, steps, world, dev)
-    assert torch.isfinite(out[:B]).all()
-    value = B * world * steps / dt
+    assert torch.isfinite(out[:B]).all() and torch.isfinite(out[-B:]).all()
+    done = sum(min(B, rows - (i % nb) * B) for i in range(steps))          # rows the timed region processed on this rank
+    value = done * world / dt
     # per sample: encoder 2 G L + heads 4 L^2 flops (MFMA-bound); 4 G bytes in, 4 T out
-    flops = (2.0 * d.G * d.L + 4.0 * d.L * d.L) * B
-    t_mfma = flops / (PEAK_F32_MFMA_TF * 1e12)
-    sec = dt / steps
+    flops = (2.0 * d.G * d.L + 4.0 * d.L * d.L) * done
+    peak = PEAK_BF16_MFMA_TF if DTYPE == "bf16" else PEAK_F32_MFMA_TF
+    # bf16: the encoder product at the bf16 peak is shorter than the stream of x through HBM, which then bounds the pass
+    t_mfma, t_hbm = flops / (peak * 1e12), 4.0 * (d.G + e.plan.T) * done / (PEAK_HBM_GBS * 1e9)
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
     del X, out
+    torch.cuda.empty_cache()
     return {
         "metric": "inference samples/sec (GO-BP OntoVAE get_pathway_activities)", "value": value, "unit": "samples/s",
-        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[3]: GOBP-syn get_pathway_activities ('act' output, [rows, 3000] fp32), "
-                               f"batches of {B} rows from {rows} HBM-resident rows per GPU", "batch_per_gpu": B,
-                   "dataset_rows": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
-        "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                     "frac": t_mfma / sec, "traffic": None, "kernel": "whole step (encoder GEMM dominates)" +
-                     (" against the fp32 MFMA peak; the encoder product itself runs on bf16 MFMA" if DTYPE == "bf16" else ""),
+        "config": {"workload": "BASELINE.json configs[3]: GOBP-syn get_pathway_activities ('act' output, [rows, 3000] fp32) over "
+                               f"{rows} HBM-resident rows per GPU in batches of {B}" + (", one pass over the whole dataset" if whole else ""),
+                   "batch_per_gpu": B, "dataset_rows": rows, "rows_timed": done, "seconds": dt,
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+        "roofline": {"bound": bound, "achieved": (flops / dt / 1e12) if bound == "mfma" else 4.0 * (d.G + e.plan.T) * done / dt / 1e9,
+                     "peak": peak if bound == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                     "frac": max(t_mfma, t_hbm) / dt, "traffic": None, "kernel": "whole pass (encoder GEMM dominates)",
                      "algorithmic_flops": flops}}
 
 
@@ -316,7 +393,7 @@ def screen_bench(a, model, dev, world, rank, steps=None, warmup=None):
                      "algorithmic_bytes": wx_bytes}}
 
 
-def train_bench(model, dev, world, rank, B, steps, warmup, rows, profile=True, single=False):
+def train_bench(model, dev, world, rank, B, steps, warmup, rows, profile=True, single=False, want_launches=False):
     """`steps` training steps at B rows per rank (global batch B * world; single=True: this rank alone, no collectives).
     Returns (seconds of the timed region [max over ranks], per-phase ms per step, dominant phase, its ms per step inside
     the timed region, its launches per step, final loss)."""
@@ -349,7 +426,7 @@ def train_bench(model, dev, world, rank, B, steps, warmup, rows, profile=True, s
     nprobe = min(10, max(warmup // 2, 1))
     for _ in range(warmup - nprobe):
         step()
-    phase_ms, dom, dom_ms_step, launches = {}, None, 0.0, 0
+    phase_ms, phase_launches, dom, dom_ms_step, launches = {}, {}, None, 0.0, 0
     cnt = C.c_int32()
     if profile:
         # the second part of the warm-up runs with every phase under HIP events: per-kernel times and the dominant phase
@@ -363,6 +440,7 @@ def train_bench(model, dev, world, rank, B, steps, warmup, rows, profile=True, s
         for ph, name in enumerate(_lib.PHASES):
             _lib.check(L.ontovae_profile_read(ph, buf, 64 * nprobe, C.byref(cnt)), "profile_read")
             phase_ms[name] = sum(buf[i] for i in range(cnt.value)) / nprobe
+            phase_launches[name] = cnt.value / nprobe
         dom = max(phase_ms, key=phase_ms.get)
         _lib.check(L.ontovae_profile_begin(1 << _lib.PHASES.index(dom), 16 * steps), "profile_begin")
     dt = _timed(step, steps, w, dev)
@@ -375,7 +453,8 @@ def train_bench(model, dev, world, rank, B, steps, warmup, rows, profile=True, s
     final = loss[:min(it[0], loss.shape[0])].cpu().numpy()
     assert np.isfinite(final).all(), "non-finite loss in the benchmark run"
     del X
-    return dt, phase_ms, dom, dom_ms_step, launches / max(steps, 1), float(final[-1, 2])
+    res = (dt, phase_ms, dom, dom_ms_step, launches / max(steps, 1), float(final[-1, 2]))
+    return res + (phase_launches,) if want_launches else res
 
 
 def main():
@@ -385,7 +464,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default: 128 on one GPU, 8192 / N on N)")
     ap.add_argument("--global-batch", type=int, default=None, help="global batch (one GPU: the whole batch on it)")
-    ap.add_argument("--rows", type=int, default=65536, help="synthetic dataset rows resident in HBM")
+    ap.add_argument("--rows", type=int, default=None, help="synthetic dataset rows resident in HBM (default: 65536 for training, "
+                                                           "1 000 000 for --mode infer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="train mode, one GPU: skip the inference / screen / global-batch legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-phase times to stderr")
@@ -426,7 +506,10 @@ def main():
     e = model._engine
     d = e.plan.dims
     if a.mode in ("infer", "screen"):
-        res = (infer_bench if a.mode == "infer" else screen_bench)(a, model, dev, world, rank)
+        if a.mode == "infer":
+            res = infer_bench(a, model, dev, world, rank, steps=None if a.steps == 200 else a.steps)
+        else:
+            res = screen_bench(a, model, dev, world, rank)
         if rank == 0:
             print(json.dumps(res))
         if world > 1:
@@ -455,51 +538,73 @@ def main():
                     f", global batch {B * world} = {world} x {B} rows")
     Bg = B * world
     nnz_t = int(e.plan.rowptr[d.C])
+    train_rows = a.rows if a.rows is not None else 65536
 
     single_same = None
     if world > 1 and scaling == "strong":
         # the curve's own baseline: the same global batch on ONE GPU (rank 0 alone; the other ranks wait at the barrier)
         if rank == 0:
             n1 = max(min(a.steps // 4, 50), 10)
-            dt1, *_ = train_bench(model, dev, world, rank, Bg, n1, 5, a.rows, profile=False, single=True)
+            dt1, *_ = train_bench(model, dev, world, rank, Bg, n1, 5, train_rows, profile=False, single=True)
             single_same = {"value": Bg * n1 / dt1, "unit": "samples/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "n_gpus": 1,
                            "global_batch": Bg}
         model, masks = build_model(dev)          # fresh weights and optimizer state on every rank
         e = model._engine
         dist.barrier()
 
-    dt, phase_ms, dom, dom_ms_step, lps, final_loss = train_bench(model, dev, world, rank, B, a.steps, a.warmup, a.rows)
+    dt, phase_ms, dom, dom_ms_step, lps, final_loss, phase_launches = train_bench(model, dev, world, rank, B, a.steps, a.warmup, train_rows,
+                                                                                  want_launches=True)
     if a.breakdown and rank == 0:
         print("per-phase ms/step (event-bracketed, includes launch gaps):", {k: round(v, 4) for k, v in phase_ms.items()},
               "sum", round(sum(phase_ms.values()), 4), file=sys.stderr)
 
     if rank == 0:
         value = Bg * a.steps / dt
-        traffic = _pmc_traffic() if (B == 128 and world == 1) else {}
+        traffic = _pmc_traffic() if (B == 128 and world == 1 and a.dtype == "f32" and a.ontology == "gobp") else {}
+        tmeta = traffic.get("_meta") if traffic else None
+        # What a bracket adds to the kernel inside it.  Launches are back to back on one stream (rocprofv3 traces: no gaps), so
+        # the un-bracketed step of the timed region is the sum of its kernels, and the brackets of the probe steps add up to
+        # that sum plus one bracket cost per launch: cost = (sum of brackets - wall step) / launches.  A bracket that holds
+        # nothing (ontovae_profile_overhead: ~3.4 us on this pool) only bounds it from above -- most of it overlaps the kernel.
+        ov_null, ov_empty = event_overhead_ms(dev)
+        n_launch = sum(max(v, 0.0) for v in phase_launches.values()) or 1.0
+        ov_est = min(max((sum(phase_ms.values()) - dt / a.steps * 1e3) / n_launch, 0.0), ov_null) if world == 1 else 0.0
         # data parallel in the gathered-dh form: every rank forms dW0 of the GLOBAL batch (parallel.py)
         from onto_vae_amd.parallel import use_gathered_dh
         dw0_rows = Bg if (world > 1 and use_gathered_dh(Bg, world, d.L, d.G)) else B
         rows_of = lambda name: dw0_rows if name == "dw0" else B
-        kernels = [r for r in (roofline_entry(n, ms, d, rows_of(n), nnz_t, traffic) for n, ms in phase_ms.items()) if r]
+        # launches per step of a phase (term levels run as one launch per level from 2048 columns on): brackets to subtract
+        launches_of = lambda name: max(phase_launches.get(name, 1.0), 1.0)
+        kernels = [r for r in (roofline_entry(n, ms, d, rows_of(n), nnz_t, traffic, a.dtype, ov_est * launches_of(n))
+                               for n, ms in phase_ms.items()) if r]
         roof = None
-        domr = roofline_entry(dom, dom_ms_step, d, rows_of(dom), nnz_t, traffic)
+        domr = roofline_entry(dom, dom_ms_step, d, rows_of(dom), nnz_t, traffic, a.dtype, ov_est * lps)
         if domr is not None:
             unit = "TFLOP/s" if domr["bound"] == "mfma" else "GB/s"
             ach = domr["TFLOPs"] if domr["bound"] == "mfma" else domr["GBps"]
-            roof = {"bound": domr["bound"], "achieved": ach, "peak": PEAK_F32_MFMA_TF if domr["bound"] == "mfma" else PEAK_HBM_GBS,
-                    "unit": unit, "frac": domr["frac"], "traffic": domr["traffic"], "kernel": dom,
-                    "kernel_ms_per_step": dom_ms_step, "launches_per_step": lps, "timer": "HIP events on the launch stream, inside the timed region",
+            roof = {"bound": domr["bound"], "achieved": ach, "peak": domr["peak"] / (1e3 if domr["bound"] == "mfma" else 1.0),
+                    "unit": unit, "frac": domr["frac"], "frac_events": domr["frac_events"], "traffic": domr["traffic"],
+                    "traffic_source": tmeta, "kernel": dom,
+                    "kernel_ms_per_step": domr["us"] * 1e-3, "kernel_ms_per_step_events": dom_ms_step,
+                    "event_bracket_overhead_ms": {"per_launch_estimate": ov_est, "null_bracket": ov_null, "empty_kernel_bracket": ov_empty},
+                    "launches_per_step": lps,
+                    "timer": "HIP events on the launch stream around every launch of the kernel inside the timed region; "
+                             "kernel_ms_per_step and frac are net of the bracket cost per launch, estimated live as (sum of all "
+                             "phases' brackets in the probe steps - wall time of an un-bracketed step) / launches per step; "
+                             "*_events are the raw brackets; null / empty-kernel brackets (ontovae_profile_overhead) are upper bounds",
                     "algorithmic_bytes": domr["algorithmic_bytes"], "algorithmic_flops": domr["algorithmic_flops"]}
         # whole-step roofline of BASELINE.md: max(F_s*B / mfma, (40 P + 4 G B) / hbm) / t_step
         P_real = d.L * d.G + 2 * d.L * d.L + int(d.nnz) + 6 * d.L + (d.C - d.L) + d.G
-        t_bound = max((2.0 * 2 * d.L * d.G + 3 * 4.0 * d.L * d.L + 3 * 2.0 * int(d.nnz)) * B / (PEAK_F32_MFMA_TF * 1e12),
+        # (bf16 variant: the two first-layer products at the bf16 peak, the rest at the fp32 one)
+        enc_peak = PEAK_BF16_MFMA_TF if a.dtype == "bf16" else PEAK_F32_MFMA_TF
+        t_bound = max(2.0 * 2 * d.L * d.G * B / (enc_peak * 1e12) + (3 * 4.0 * d.L * d.L + 3 * 2.0 * int(d.nnz)) * B / (PEAK_F32_MFMA_TF * 1e12),
                       (40.0 * P_real + 4.0 * d.G * B) / (PEAK_HBM_GBS * 1e9))
         out = {"metric": "train samples/sec (GO-BP OntoVAE fwd+bwd+step)", "value": value, "unit": "samples/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": workload, "batch_per_gpu": B, "global_batch": Bg, "dataset_rows": max(a.rows, Bg),
+               "config": {"workload": workload, "batch_per_gpu": B, "global_batch": Bg, "dataset_rows": max(train_rows, Bg),
                           "parallelism": f"dp{world}" if world > 1 else "single"},
-               "roofline": roof, "step_roofline_frac": t_bound / (dt / a.steps),
+               "roofline": roof, "step_roofline_frac": t_bound / (dt / a.steps), "step_roofline_bound_ms": t_bound * 1e3,
                "roofline_kernels": kernels,
                "phase_ms_per_step": {k: round(v, 5) for k, v in phase_ms.items()},
                "final_loss": final_loss}
@@ -510,19 +615,20 @@ def main():
         if world == 1 and not a.no_extras and B == 128 and a.global_batch is None and a.dtype == "f32" and a.ontology == "gobp":
             # the other headline workloads, measured after the timed region so that the driver's run covers them too
             xa = argparse.Namespace(**vars(a))
-            xa.batch, xa.rows = None, 65536
-            inf = infer_bench(xa, model, dev, 1, 0, steps=20, warmup=3)
+            xa.batch, xa.rows = None, None
+            inf = infer_bench(xa, model, dev, 1, 0, steps=None, warmup=3, rows=INFER_ROWS)
             out["inference"] = {k: inf[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline")}
             out["inference_from_host"] = host_infer_bench(model, dev)
             scr = screen_bench(xa, model, dev, 1, 0, steps=100, warmup=10)
             out["screen"] = {k: scr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline")}
             m2, _ = build_model(dev)
             n1 = 30
-            dt1, ph1, *_ = train_bench(m2, dev, 1, 0, GLOBAL_BATCH, n1, 6, a.rows)
+            dt1, ph1, _, _, _, _, pl1 = train_bench(m2, dev, 1, 0, GLOBAL_BATCH, n1, 6, train_rows, want_launches=True)
             out["global_batch_8192_single_gpu"] = {
                 "metric": "train samples/sec at configs[2]'s global batch on one GPU", "value": GLOBAL_BATCH * n1 / dt1,
                 "unit": "samples/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1,
-                "roofline_kernels": [r for r in (roofline_entry(n, ms, d, GLOBAL_BATCH, nnz_t, {}) for n, ms in ph1.items()) if r]}
+                "roofline_kernels": [r for r in (roofline_entry(n, ms, d, GLOBAL_BATCH, nnz_t, {}, "f32", 0.0)
+                                                 for n, ms in ph1.items()) if r]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(masks, 128)
         print(json.dumps(out))

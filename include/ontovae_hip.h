@@ -535,6 +535,10 @@ enum {
 int ontovae_profile_begin(uint32_t phase_mask, int32_t capacity);
 int ontovae_profile_read(int32_t phase, float* ms, int32_t cap, int32_t* n_out);
 int ontovae_profile_end(void);
+/* What a bracket costs by itself, on `stream`, with events of the kind the brackets use: the mean elapsed milliseconds
+ * between the two events of `n` brackets that hold NOTHING (null_ms) and of `n` that hold one launch of a kernel of one
+ * wave that does nothing (empty_ms).  bench.py reports kernel times net of null_ms next to the raw ones.  Synchronises. */
+int ontovae_profile_overhead(void* stream, int32_t n, float* null_ms, float* empty_ms);
 
 #ifdef __cplusplus
 }

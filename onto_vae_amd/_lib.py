@@ -148,6 +148,7 @@ def lib():
         "ontovae_profile_begin": [C.c_uint32, i32],
         "ontovae_profile_read": [i32, c_f32p, i32, c_i32p],
         "ontovae_profile_end": [],
+        "ontovae_profile_overhead": [vp, i32, c_f32p, c_f32p],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -179,7 +180,7 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_wilcoxon_workspace_bytes", "ontovae_wilcoxon_zsplit", "ontovae_fdr_workspace_bytes", "ontovae_fdr_bh", "ontovae_fdr_bh_static",
             "ontovae_to_feature_major",
             "ontovae_vae_layout", "ontovae_vae_workspace_bytes", "ontovae_vae_train_step", "ontovae_vae_forward", "ontovae_vae_adamw_apply",
-            "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end"]
+            "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end", "ontovae_profile_overhead"]
 
 FLAG_BF16_GEMM = 32
 FLAG_CB_GENE_FWD = 128       # training forward of the gene layer on 32-column blocks instead of the LDS-panel kernel (tests compare the two)

@@ -97,6 +97,39 @@ extern "C" int ontovae_profile_read(int32_t phase, float* ms, int32_t cap, int32
     return ONTOVAE_OK;
 }
 
+__global__ void ov_empty_kernel() {}
+
+extern "C" int ontovae_profile_overhead(void* stream, int32_t n, float* null_ms, float* empty_ms) {
+    if (n < 1 || n > 4096 || !null_ms || !empty_ms) { ontovae_set_error("profile_overhead: bad arguments"); return ONTOVAE_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t* ev = new hipEvent_t[4 * n];
+    for (int i = 0; i < 4 * n; ++i) {
+        hipError_t e_ = hipEventCreateWithFlags(&ev[i], hipEventDisableSystemFence);
+        if (e_ != hipSuccess) { for (int j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]); delete[] ev; ontovae_set_error("profile_overhead: hipEventCreateWithFlags failed: %s", hipGetErrorString(e_)); return ONTOVAE_EHIP; }
+    }
+    for (int i = 0; i < n; ++i) {
+        (void)hipEventRecord(ev[4 * i], st);
+        (void)hipEventRecord(ev[4 * i + 1], st);
+        (void)hipEventRecord(ev[4 * i + 2], st);
+        hipLaunchKernelGGL(ov_empty_kernel, dim3(1), dim3(64), 0, st);
+        (void)hipEventRecord(ev[4 * i + 3], st);
+    }
+    hipError_t err = hipStreamSynchronize(st);
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < n && err == hipSuccess; ++i) {
+        float t = 0.f;
+        err = hipEventElapsedTime(&t, ev[4 * i], ev[4 * i + 1]);
+        a += t;
+        if (err == hipSuccess) { err = hipEventElapsedTime(&t, ev[4 * i + 2], ev[4 * i + 3]); b += t; }
+    }
+    for (int i = 0; i < 4 * n; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
+    if (err != hipSuccess) { ontovae_set_error("profile_overhead: %s", hipGetErrorString(err)); return ONTOVAE_EHIP; }
+    *null_ms = (float)(a / n);
+    *empty_ms = (float)(b / n);
+    return ONTOVAE_OK;
+}
+
 static inline int ov_vec(int B) { return B <= 64 ? 1 : (B <= 128 ? 2 : 4); }
 static inline int ov_ldb(int B) {
     const int q = 64 * ov_vec(B);

@@ -13,6 +13,8 @@ row 12); the contract is that an R-rank step equals the single-device step on th
 No collective is on the inference path: samples are independent, ranks take disjoint slices.
 """
 import os
+import queue
+import threading
 
 import torch
 import torch.distributed as dist
@@ -25,31 +27,114 @@ class _Done:
 
 def _stream_ordered(group):
     """nccl (RCCL) collectives are ordered on streams and may be left outstanding.  Any other backend (gloo: the CPU and
-    2-process tests) gets host tensors: gloo's own handling of device tensors was seen to stall when two processes share one
-    GPU, so device buffers are staged through the host here, one completed collective at a time."""
+    2-process tests) reaches device buffers through _HostStaged below."""
     return dist.get_backend(group) == "nccl"
 
 
+class _Staged:
+    """Handle of one collective of _HostStaged.  wait(): the caller's stream is ordered after the copy back to the device
+    (as RCCL's Work.wait() orders it after the collective); the host blocks only until the worker has enqueued that copy."""
+
+    def __init__(self):
+        self.done = threading.Event()
+        self.back = None
+        self.error = None
+
+    def wait(self):
+        self.done.wait()
+        if self.error is not None:
+            raise self.error
+        if self.back is not None:
+            torch.cuda.current_stream(self.back_device).wait_event(self.back)
+
+
+class _HostStaged:
+    """RCCL's calling convention on top of a host backend (gloo), for device tensors: a collective is issued against what is
+    on the compute stream at the moment of the call, runs in the background while the caller keeps launching kernels, and is
+    complete for the caller's stream after wait().  One worker thread per process takes the calls in issue order (the order is
+    the same on every rank, as a communicator's order is): it waits for the issue-time event on a copy stream, copies the
+    buffer into a pinned mirror, runs the collective on the mirror, copies the result back in place and records an event.
+
+    Why not hand gloo the device tensors: its own staging of them stalled with two processes on one GPU (DESIGN.md section 5
+    has what is known); and staging every collective synchronously, as round 2 did, never left a handle outstanding under
+    later launches, so ordering and buffer-reuse errors of the panel loop could not show before an 8-GPU run."""
+
+    _inst = {}
+
+    @classmethod
+    def get(cls, device):
+        key = (device.type, device.index)
+        if key not in cls._inst:
+            cls._inst[key] = cls(device)
+        return cls._inst[key]
+
+    def __init__(self, device):
+        self.device = device
+        self.q = queue.Queue()
+        self.copy_stream = torch.cuda.Stream(device)
+        self.mirrors = {}                       # numel -> free pinned float buffers (allocated on the caller's thread)
+        self.thread = threading.Thread(target=self._run, name="ontovae-host-staged", daemon=True)
+        self.thread.start()
+
+    def _mirror(self, t):
+        free = self.mirrors.setdefault((t.numel(), t.dtype), [])
+        return free.pop() if free else torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+
+    def submit(self, kind, t, out, group):
+        h = _Staged()
+        h.back_device = self.device
+        issued = torch.cuda.Event()
+        issued.record(torch.cuda.current_stream(self.device))
+        h.back = torch.cuda.Event()
+        self.q.put((kind, t, out, group, issued, self._mirror(t), self._mirror(out) if out is not None else None, h))
+        return h
+
+    def _run(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            kind, t, out, group, issued, ht, ho, h = self.q.get()
+            try:
+                with torch.cuda.stream(self.copy_stream):
+                    self.copy_stream.wait_event(issued)
+                    ht.copy_(t.detach().reshape(-1), non_blocking=True)
+                    self.copy_stream.synchronize()
+                    if kind == "all_reduce":
+                        dist.all_reduce(ht, group=group)
+                        t.detach().reshape(-1).copy_(ht, non_blocking=True)
+                    else:
+                        dist.all_gather_into_tensor(ho, ht, group=group)
+                        out.detach().reshape(-1).copy_(ho, non_blocking=True)
+                    h.back.record(self.copy_stream)
+                    # the mirrors may be reused once the copy back has left them
+                    self.copy_stream.synchronize()
+                self.mirrors[(ht.numel(), ht.dtype)].append(ht)
+                if ho is not None:
+                    self.mirrors[(ho.numel(), ho.dtype)].append(ho)
+            except BaseException as e:          # surfaced by wait()
+                h.error = e
+            h.done.set()
+
+
 def all_reduce(t, group=None, async_op=False):
+    """SUM all-reduce of `t` in place.  Device tensors must be contiguous.  Returns a handle with wait()."""
     if _stream_ordered(group):
         return dist.all_reduce(t, group=group, async_op=async_op) or _Done()
-    if t.is_cuda:
-        h = t.detach().cpu()
-        dist.all_reduce(h, group=group)
-        t.copy_(h)
-    else:
-        dist.all_reduce(t, group=group)
-    return _Done()
+    if not t.is_cuda:
+        return dist.all_reduce(t, group=group, async_op=async_op) or _Done()
+    if not t.is_contiguous():
+        raise ValueError("all_reduce of a device tensor needs a contiguous tensor")
+    h = _HostStaged.get(t.device).submit("all_reduce", t, None, group)
+    if not async_op:
+        h.wait()
+        return _Done()
+    return h
 
 
 def all_gather_into_tensor(out, t, group=None):
     if _stream_ordered(group) or not t.is_cuda:
         dist.all_gather_into_tensor(out, t, group=group)
         return
-    h = t.detach().cpu()
-    ho = torch.empty(out.shape, dtype=out.dtype)
-    dist.all_gather_into_tensor(ho, h, group=group)
-    out.copy_(ho)
+    _HostStaged.get(t.device).submit("all_gather", t, out, group).wait()
 
 
 def shard_bounds(B, world, rank):

@@ -34,6 +34,7 @@ Reference map (paths relative to /root/reference):
                           biased variance for normalisation, unbiased for running_var
 """
 import math
+import time
 
 import numpy as np
 
@@ -107,6 +108,7 @@ class OracleOntoVAE:
         self.buf = {}        # BN buffers
         self.opt = None      # AdamW state
         self.training = True
+        self.phase_seconds = None      # bench.py's cpu_baseline: dict that train_step fills (forward / backward / grad_mask / adamw / clamp)
 
     # ------------------------------------------------------------------ state
     def param_names(self):
@@ -218,6 +220,8 @@ class OracleOntoVAE:
         z = (mu + eps * sigma).astype(self.dt)
         recon, outs, _ = self.decoder_forward(z, collect=True)
         rec, kl, loss = self.vae_loss(recon, mu, lv, x, kl_coeff)
+        if self.phase_seconds is not None:      # the encoder part of the forward was timed by train_step's bracket; see there
+            self.phase_seconds["_fwd_end"] = time.perf_counter()
 
         g = {}
         d_c = self.dt(2) * (recon - x)                                  # d loss / d recon
@@ -281,16 +285,29 @@ class OracleOntoVAE:
 
     def apply_step(self, g, lr):
         """Gradient mask, AdamW and clamp of one train_round body (vae_model.py:168-176) on gradients from gradients()."""
+        ph, t0 = self.phase_seconds, time.perf_counter()
         for i in range(self.K):                                     # vae_model.py:168-169
             g[f"decoder.decoder.{i}.0.weight"] *= self.masks[i]
+        t1 = time.perf_counter()
         self.adamw(g, lr)                                           # vae_model.py:172
+        t2 = time.perf_counter()
         for i in range(self.K):                                     # vae_model.py:175-176
             n = f"decoder.decoder.{i}.0.weight"
             self.p[n] = np.maximum(self.p[n], self.dt(0))
+        if ph is not None:
+            for k, v in (("grad_mask", t1 - t0), ("adamw", t2 - t1), ("clamp", time.perf_counter() - t2)):
+                ph[k] = ph.get(k, 0.0) + v
 
     def train_step(self, x, eps, lr, kl_coeff, scales=None):
-        """One body of train_round (vae_model.py:156-176).  Returns (rec, kl, loss)."""
+        """One body of train_round (vae_model.py:156-176).  Returns (rec, kl, loss).  With self.phase_seconds a dict, the
+        wall time of the five phases BASELINE.md's CPU protocol names is added to it: forward (encoder, decoder, loss),
+        backward, grad_mask, adamw, clamp."""
+        ph, t0 = self.phase_seconds, time.perf_counter()
         rec, kl, loss, g = self.gradients(x, eps, kl_coeff, scales)
+        if ph is not None:
+            t1, tf = time.perf_counter(), ph.pop("_fwd_end")
+            ph["forward"] = ph.get("forward", 0.0) + (tf - t0)
+            ph["backward"] = ph.get("backward", 0.0) + (t1 - tf)
         self.apply_step(g, lr)
         return rec, kl, loss
 

@@ -40,6 +40,8 @@ def main():
     torch.manual_seed(0)
     model = OntoVAE(onto, "d", neuronnum=int(z["nu"]), drop=0.0, z_drop=0.0)
     model.to("cuda:0")
+    if os.environ.get("ONTOVAE_DP_WORKER_PRECISION") == "bf16":      # BASELINE.json configs[4]: the bf16-MFMA variant, data parallel
+        model.set_precision("bf16")
     model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
     del sd
     X = torch.as_tensor(Xh).cuda()
@@ -54,6 +56,35 @@ def main():
     if trace:
         import time
         print(f"[dp_worker {rank}] model ready at {time.time():.1f}", file=sys.stderr, flush=True)
+    calls = []
+    if os.environ.get("ONTOVAE_DP_WORKER_CALLS") == "1":
+        # the order in which a step issues collectives, launches the row panels of dW0 and waits: what must stay outstanding
+        # under which launches is a property of this sequence (tests/test_gpu_configs.py::test_dp_async_handles_*)
+        from onto_vae_amd import parallel
+        from onto_vae_amd.engine import Engine
+        staged = parallel._HostStaged.get(torch.device("cuda", 0))
+        submit0, dw0_rows0, apply0 = staged.submit, Engine.dw0_rows, Engine.adamw_apply_range
+
+        def submit(kind, t, out, group):
+            h = submit0(kind, t, out, group)
+            tag = f"{kind}:{t.numel()}"
+            calls.append("issue " + tag)
+            wait0 = h.wait
+
+            def wait():
+                calls.append(("wait " if h.done.is_set() else "wait(pending) ") + tag)
+                wait0()
+            h.wait = wait
+            return h
+
+        def dw0_rows(self, x, xidx, l0, l1):
+            calls.append(f"dw0_rows {l0}:{l1}")
+            return dw0_rows0(self, x, xidx, l0, l1)
+
+        def apply_range(self, adam, begin, end):
+            calls.append(f"adamw {begin}:{end}")
+            return apply0(self, adam, begin, end)
+        staged.submit, Engine.dw0_rows, Engine.adamw_apply_range = submit, dw0_rows, apply_range
     losses = torch.zeros(steps, 3, device="cuda")
     for s in range(steps):
         ii = idx[s * B:(s + 1) * B]
@@ -65,7 +96,7 @@ def main():
             torch.cuda.synchronize()
             print(f"[dp_worker {rank}] step {s} done at {time.time():.1f}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
-    np.savez(path + f".rank{rank}.npz", P=model._engine.P.cpu().numpy(), losses=losses.cpu().numpy())
+    np.savez(path + f".rank{rank}.npz", P=model._engine.P.cpu().numpy(), losses=losses.cpu().numpy(), calls=np.array(calls, dtype=str))
     dist.destroy_process_group()
 
 

@@ -233,6 +233,68 @@ def test_gobp_syn_full_size_properties():
     assert float((out.cpu() - act[:4096]).abs().max()) <= 2e-5 * float(act.abs().max())
 
 
+def test_inference_one_million_rows():
+    """BASELINE.json configs[3] at its stated size: get_pathway_activities-equivalent over
+    1 000 000 GOBP-syn samples generated ON THE DEVICE in chunks from a seeded generator (80 GB of X, resident), streamed in
+    batches of 16384 rows into a resident [1 M, 3000] output (12 GB) by OntoVAE._pass_data.  The reference's path
+    (vae_model.py:330-361) moves the dataset to the device in one tensor; no oracle pass covers 1 M rows, so: rows sampled
+    from the first, a middle and the last (partial) batch against oracle.pass_data with the same eps, and the size-independent
+    properties -- every row finite, rows independent of their batch (windows re-run at another batch size), and of their
+    position (a window re-run on its own)."""
+    from ontovae_oracle import OracleOntoVAE
+    masks, sd, _ = gobp()
+    N, G, L, T, step = 1_000_000, 20000, 360, 3000, 16384
+    model, _ = make_model(masks, 3, sd, X=np.zeros((4, G), np.float32))
+    model.eval()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20250117)
+    X = torch.empty(N, G, dtype=torch.float32, device="cuda")
+    for i in range(0, N, 8192):
+        n = min(8192, N - i)
+        X[i:i + n] = torch.log1p(torch.poisson(torch.full((n, G), 0.3, device="cuda"), generator=gen))
+    # eps per batch from a seeded device generator; the batches the oracle will look at keep theirs
+    nb = (N + step - 1) // step
+    watch = {0: None, nb // 2: None, nb - 1: None}
+    egen = torch.Generator(device="cuda")
+    egen.manual_seed(7)
+    calls = [0]
+
+    def eps_source(B):
+        e = torch.randn(B, L, generator=egen, device="cuda")
+        b, which = divmod(calls[0], 2)
+        if b in watch:
+            watch[b] = (watch[b] or ()) + (e[:48].cpu().numpy(),)
+        calls[0] += 1
+        return e
+
+    model.eps_source = eps_source
+    model.inference_batch = step
+    act = model._pass_data(X, 'act')
+    assert calls[0] == 2 * nb and N % step == 576
+    assert act.shape == (N, T) and act.dtype == np.float32
+    # every row finite (checked in slabs: the array is 12 GB)
+    for i in range(0, N, 100000):
+        assert np.isfinite(act[i:i + 100000]).all()
+    o = OracleOntoVAE(masks, 3)
+    o.load_state_dict(sd)
+    for b, (e1, e2) in watch.items():
+        rows = slice(b * step, b * step + 48)
+        want = o.pass_data(X[rows].cpu().numpy(), e1, e2, "act_only")
+        assert act_close(act[rows], want), b
+    # rows do not depend on their batch or their position: windows re-run alone, in batches of 4096 rows, with eps = 0 on both
+    # sides (the first pass's draws are keyed by call order); the full-size pass is repeated with eps = 0 for that
+    zero = torch.zeros(step, L, device="cuda")
+    model.eps_source = lambda B: zero[:B]
+    act0 = model._pass_data(X, 'act')
+    scale = float(np.abs(act0[:step]).max())
+    model.inference_batch = 4096
+    for lo in (0, (nb // 2) * step + 1000, N - 5000):
+        win = model._pass_data(X[lo:lo + 5000], 'act')
+        assert np.abs(win - act0[lo:lo + 5000]).max() <= 2e-5 * scale, lo
+    # and the draws matter: the eps = 0 pass differs from the first one in the latent columns
+    assert np.abs(act0[:64, :120] - act[:64, :120]).max() > 1e-3
+
+
 # ---------------------------------------------------------------------------------------------- configs[0]
 PWO_COUNTS = [76, 3, 12, 131, 169, 160, 101, 5]      # SURVEY.md 0.3: terms per depth of the trimmed Pathway Ontology
 
@@ -426,6 +488,74 @@ def test_dp_two_processes_gobp_syn_heuristic_forms(tmp_path, B, form):
     assert (diff > 1e-6 + 1e-4 * np.abs(want[mask])).mean() <= 0.01 and diff.max() <= 2 * 1e-4
 
 
+def test_dp_async_handles_stay_outstanding_under_the_panel_products(tmp_path):
+    """The asynchronous control flow of the all-reduce form against a real peer: two processes on GPU 0, gloo behind the
+    stream-ordered staging of onto_vae_amd.parallel._HostStaged (a collective is issued against what is on the compute stream,
+    runs on a worker thread while the caller keeps launching, completes for the stream at wait()).  Two steps at global batch
+    8192 on the full-size model.  Checked: (1) the order of issue / launch / wait in a step -- the [heads | decoder] bucket is
+    issued before the first row panel of dW0, panel p's all-reduce right after its product and before panel p + 1's product,
+    no wait before the last product is launched, AdamW of a range only after that range's wait; (2) the result: replicas
+    bitwise identical and equal to the single-process steps -- a buffer overwritten while its all-reduce was outstanding, or
+    an update applied before its exchange completed, lands somewhere else."""
+    from onto_vae_amd.parallel import use_gathered_dh, w0_row_panels
+    from onto_vae_amd.vae_model import FusedAdamW
+    B, steps = 8192, 2
+    assert not use_gathered_dh(B, 2, 360, 20000)
+    masks, sd, X = gobp()
+    rng = np.random.RandomState(4242)
+    idx = rng.randint(0, X.shape[0], size=B * steps).astype(np.int32)
+    eps = rng.standard_normal((steps, B, 360)).astype(np.float32)
+    path = str(tmp_path / "dp_async.npz")
+    np.savez(path, gobp=1, nu=3, idx=idx, eps=eps, B=B, lr=1e-4, use_idx=1)
+    ref, _ = make_model(masks, 3, sd)
+    ropt = FusedAdamW(ref, lr=1e-4)
+    rl = torch.zeros(steps, 3, device="cuda")
+    Xd = torch.as_tensor(X).cuda()
+    for s in range(steps):
+        ref._engine.train_step(Xd, torch.as_tensor(idx[s * B:(s + 1) * B]).cuda(), torch.as_tensor(eps[s]), 1e-4, ropt.next_hyper(), rl[s])
+    want = ref._engine.P.cpu().numpy()
+    lay, Lw, G = ref._engine.plan.layout, ref._engine.plan.L, ref._engine.plan.G
+    del ref, Xd
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("ONTOVAE_DP_ALLREDUCE", "ONTOVAE_DP_TWO_EXCHANGES", "ONTOVAE_DP_W0_PANELS")}
+    env["ONTOVAE_DP_WORKER_CALLS"] = "1"
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker.py")
+    port = str(29800 + (os.getpid() % 90))
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, path, str(steps)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=170) == 0
+    got = [np.load(path + f".rank{r}.npz") for r in range(2)]
+    assert np.array_equal(got[0]["P"], got[1]["P"])
+    np.testing.assert_allclose(got[0]["losses"], rl.cpu().numpy(), rtol=2e-5)
+    mask = np.ones(want.shape, bool)
+    mask[int(lay.b0):int(lay.b0) + Lw] = False
+    diff = np.abs(got[0]["P"] - want)[mask]
+    assert (diff > 1e-6 + 1e-4 * np.abs(want[mask])).mean() <= 0.01 and diff.max() <= 2 * steps * 1e-4
+    panels = w0_row_panels(Lw, 2)
+    assert len(panels) == 4
+    early = int(lay.total) - int(lay.Wh)
+    small = int(lay.Wh) - int(lay.b0)
+    for r in range(2):
+        calls = [str(c).replace("wait(pending) ", "wait ") for c in got[r]["calls"]]
+        per_step = len(calls) // steps
+        assert per_step * steps == len(calls)
+        for s in range(steps):
+            c = calls[s * per_step:(s + 1) * per_step]
+            want_seq = [f"issue all_gather:{2 * Lw + 1}", f"wait all_gather:{2 * Lw + 1}",          # SyncBN forward statistics
+                        f"issue all_reduce:{2 * Lw}", f"wait all_reduce:{2 * Lw}",                    # SyncBN backward sums
+                        f"issue all_reduce:{early}"]                                                 # [heads | decoder], left outstanding
+            for l0, l1 in panels:
+                want_seq += [f"dw0_rows {l0}:{l1}", f"issue all_reduce:{(l1 - l0) * G}"]
+            want_seq += [f"issue all_reduce:{small}"]
+            for l0, l1 in panels:
+                want_seq += [f"wait all_reduce:{(l1 - l0) * G}", f"adamw {int(lay.W0) + l0 * G}:{int(lay.W0) + l1 * G}"]
+            want_seq += [f"wait all_reduce:{small}", f"wait all_reduce:{early}", f"adamw {int(lay.b0)}:{int(lay.total)}",
+                         "issue all_reduce:3", "wait all_reduce:3"]
+            assert c == want_seq, (r, s, c)
+    # at least one wait found its collective still running when it was called: the handles are real
+    assert any(str(c).startswith("wait(pending)") for r in range(2) for c in got[r]["calls"])
+
+
 # ---------------------------------------------------------------------------------------------- configs[4], bf16 variant
 BF16_LOSS_REL = 2e-2        # stated tolerance of the bf16-MFMA variant against the float32 oracle: loss per step
 BF16_ACT_COS = 0.999        # pathway activities / reconstructions: cosine per sample
@@ -499,6 +629,104 @@ def test_bf16_variant_vs_oracle(which):
     w_hip, w_ref, w0 = m3._engine.view("W0").cpu().numpy(), o3.p["encoder.encoder.0.0.weight"], np.asarray(sd["encoder.encoder.0.0.weight"])
     du_h, du_r = (w_hip - w0).ravel(), (w_ref - w0).ravel()
     assert float(du_h @ du_r / (np.linalg.norm(du_h) * np.linalg.norm(du_r))) >= 0.9      # Adam's sign-like steps agree on most weights
+
+
+@pytest.mark.parametrize("size,form", [("medium", "allreduce"), ("medium", "gathered"), ("gobp", "allreduce")])
+def test_bf16_variant_data_parallel_two_processes(tmp_path, size, form):
+    """BASELINE.json configs[4] as stated: the bf16-MFMA variant UNDER data parallel.  onto_vae_amd.parallel.dp_train_step in two
+    processes on GPU 0 with set_precision('bf16'); the all-reduce form forms dW0 in row panels through ontovae_dw0_rows' bf16
+    branch (the transposed bf16 copy of x that phase 0 left behind), the gathered form keeps dW0 in fp32 and takes only the
+    forward product in bf16.  Replicas must stay bitwise identical and land where the single-process bf16 steps on the global
+    batch land (itself held to the oracle at the variant's stated tolerance in test_bf16_variant_vs_oracle): the partition
+    changes only fp32 summation order, not which values are rounded to bf16."""
+    from onto_vae_amd.vae_model import FusedAdamW
+    if size == "medium":
+        masks, sd = medium()
+        rng = np.random.RandomState(88)
+        B, steps, lr, L = 512, 2, 1e-3, 60
+        X = np.log1p(rng.poisson(0.5, size=(2048, 1000))).astype(np.float32)
+        idx = rng.permutation(2048)[:B * steps].astype(np.int32)
+        eps = rng.standard_normal((steps, B, L)).astype(np.float32)
+        path = str(tmp_path / "dp_bf16.npz")
+        np.savez(path, nmask=len(masks), nu=3, X=X, idx=idx, eps=eps, B=B, lr=lr, use_idx=1,
+                 **{f"mask{i}": m for i, m in enumerate(masks)}, **{"sd:" + k: np.asarray(v) for k, v in sd.items()})
+    else:
+        masks, sd, X = gobp()
+        rng = np.random.RandomState(8192 + 16)
+        B, steps, lr, L = 8192, 1, 1e-4, 360
+        idx = rng.randint(0, X.shape[0], size=B).astype(np.int32)
+        eps = rng.standard_normal((steps, B, L)).astype(np.float32)
+        path = str(tmp_path / "dp_bf16_gobp.npz")
+        np.savez(path, gobp=1, nu=3, idx=idx, eps=eps, B=B, lr=lr, use_idx=1)
+    ref, _ = make_model(masks, 3, sd)
+    ref.set_precision("bf16")
+    ropt = FusedAdamW(ref, lr=lr)
+    rl = torch.zeros(steps, 3, device="cuda")
+    Xd = torch.as_tensor(X).cuda()
+    for s in range(steps):
+        ref._engine.train_step(Xd, torch.as_tensor(idx[s * B:(s + 1) * B]).cuda(), torch.as_tensor(eps[s]), 1e-4, ropt.next_hyper(), rl[s])
+    want = ref._engine.P.cpu().numpy()
+    lay, Lw = ref._engine.plan.layout, ref._engine.plan.L
+    w0_before = np.asarray(sd["encoder.encoder.0.0.weight"], np.float32).ravel()
+    # the flag is live: the same first step in float32 moves W0 differently (Adam's first step is lr * sign(g): every
+    # gradient element whose sign the bf16 rounding flips shows)
+    f32, _ = make_model(masks, 3, sd)
+    fl = torch.zeros(3, device="cuda")
+    f32._engine.train_step(Xd, torch.as_tensor(idx[:B]).cuda(), torch.as_tensor(eps[0]), 1e-4, FusedAdamW(f32, lr=lr).next_hyper(), fl)
+    if steps == 1:
+        assert not torch.equal(f32._engine.view("W0"), ref._engine.view("W0"))
+    else:
+        assert abs(float(fl[2]) - float(rl[0, 2])) > 1e-7 * abs(float(fl[2]))
+    del ref, f32, Xd
+    torch.cuda.empty_cache()
+    env = dict(os.environ, ONTOVAE_DP_ALLREDUCE="1" if form == "allreduce" else "0", ONTOVAE_DP_WORKER_PRECISION="bf16")
+    env.pop("ONTOVAE_DP_TWO_EXCHANGES", None)
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker.py")
+    port = str(29500 + (os.getpid() % 90))
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, path, str(steps)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=170) == 0
+    got = [np.load(path + f".rank{r}.npz") for r in range(2)]
+    assert np.array_equal(got[0]["P"], got[1]["P"])
+    np.testing.assert_allclose(got[0]["losses"], rl.cpu().numpy(), rtol=2e-5)
+    mask = np.ones(want.shape, bool)
+    mask[int(lay.b0):int(lay.b0) + Lw] = False
+    w0 = slice(int(lay.W0), int(lay.W0) + Lw * masks[-1].shape[0])
+    if form == "gathered":
+        # this form keeps dW0 = dh x in float32 on every rank (DESIGN.md section 3, bf16 variant) while the single-process
+        # bf16 step forms it from bf16 operands: W0 moves the same way (Adam's sign-like steps) inside the Adam bound, every
+        # other parameter sees identical arithmetic and is held tightly
+        du_g, du_w = (got[0]["P"][w0] - w0_before).astype(np.float64), (want[w0] - w0_before).astype(np.float64)
+        assert np.abs(got[0]["P"][w0] - want[w0]).max() <= 2 * steps * lr
+        assert float(du_g @ du_w / (np.linalg.norm(du_g) * np.linalg.norm(du_w))) >= 0.9
+        mask[w0] = False
+    diff = np.abs(got[0]["P"] - want)[mask]
+    assert (diff > 1e-6 + 1e-4 * np.abs(want[mask])).mean() <= 0.01 and diff.max() <= 2 * steps * lr
+
+
+@pytest.mark.parametrize("args", [[], ["--global-batch", "1024"], ["--global-batch", "2048", "--dtype", "bf16"]])
+def test_bench_line_is_self_consistent(args):
+    """bench.py's JSON line on short runs: every launch of the step has a roofline entry whose fraction of peak is in (0, 1]
+    (the cost model charges no launch more than the hardware could move, at any batch regime or dtype), the dominant kernel's
+    entry carries both the raw event time and the one net of the bracket cost, and the two differ by less than 10 %."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "10", "--no-extras", "--no-cpu-baseline"] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=160, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    names = {k["kernel"] for k in d["roofline_kernels"]}
+    assert {"enc_gemm", "bn_fwd", "heads", "reparam", "dec_fwd_terms", "dec_fwd_gene", "dec_bwd_gene", "dec_bwd", "latent_bwd",
+            "da_gemm", "dwh", "dw0"} <= names
+    for k in d["roofline_kernels"]:
+        assert 0.0 < k["frac"] <= 1.0 and "exceeds_peak" not in k, k
+        assert k["frac_events"] <= k["frac"]
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and 0.0 < roof["frac"] <= 1.0
+    assert roof["kernel_ms_per_step"] <= roof["kernel_ms_per_step_events"] <= 1.1 * roof["kernel_ms_per_step"]
+    assert d["dtype"] == ("bf16" if "bf16" in args else "f32") and 0.0 < d["step_roofline_frac"] <= 1.0
+    if "bf16" in args:
+        assert any(k["kernel"] == "enc_gemm" and (k["bound"] == "hbm" or k["peak"] == 2.5e6) for k in d["roofline_kernels"])
 
 
 def test_bench_multi_rank_code_path_rehearsal():
