@@ -115,9 +115,14 @@ class _HostStaged:
             h.done.set()
 
 
+def _direct(group):
+    """ONTOVAE_DP_GLOO_DEVICE=1 (diagnosis only, profiling/dp_hang_probe.sh): hand the host backend the device tensors."""
+    return _stream_ordered(group) or os.environ.get("ONTOVAE_DP_GLOO_DEVICE") == "1"
+
+
 def all_reduce(t, group=None, async_op=False):
     """SUM all-reduce of `t` in place.  Device tensors must be contiguous.  Returns a handle with wait()."""
-    if _stream_ordered(group):
+    if _direct(group):
         return dist.all_reduce(t, group=group, async_op=async_op) or _Done()
     if not t.is_cuda:
         return dist.all_reduce(t, group=group, async_op=async_op) or _Done()
@@ -131,7 +136,7 @@ def all_reduce(t, group=None, async_op=False):
 
 
 def all_gather_into_tensor(out, t, group=None):
-    if _stream_ordered(group) or not t.is_cuda:
+    if _direct(group) or not t.is_cuda:
         dist.all_gather_into_tensor(out, t, group=group)
         return
     _HostStaged.get(t.device).submit("all_gather", t, out, group).wait()

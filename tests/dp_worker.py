@@ -20,6 +20,11 @@ def main():
     if backend == "nccl":
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    elif os.environ.get("ONTOVAE_DP_WORKER_GLOO_THREADS"):         # diagnosis (profiling/dp_hang_probe.sh): gloo's worker-thread count
+        opts = dist.ProcessGroupGloo._Options()
+        opts._threads = int(os.environ["ONTOVAE_DP_WORKER_GLOO_THREADS"])
+        opts._devices = [dist.ProcessGroupGloo.create_default_device()]
+        dist.init_process_group("gloo", rank=rank, world_size=world, pg_options=opts)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from onto_vae_amd.synthetic import StubOntobj
@@ -85,6 +90,19 @@ def main():
             calls.append(f"adamw {begin}:{end}")
             return apply0(self, adam, begin, end)
         staged.submit, Engine.dw0_rows, Engine.adamw_apply_range = submit, dw0_rows, apply_range
+    if os.environ.get("ONTOVAE_DP_WORKER_WATCHDOG"):
+        # diagnosis (profiling/dp_hang_probe.sh): after N seconds report, without blocking, whether everything launched on the
+        # compute stream has finished (hipStreamQuery) -- a stalled collective with an idle compute stream is not a stalled kernel
+        import threading
+        import time as _t
+
+        def watch():
+            _t.sleep(float(os.environ["ONTOVAE_DP_WORKER_WATCHDOG"]))
+            torch.cuda.set_device(0)
+            for i in range(3):
+                print(f"[dp_worker {rank}] watchdog: compute stream idle = {torch.cuda.default_stream().query()}", file=sys.stderr, flush=True)
+                _t.sleep(5)
+        threading.Thread(target=watch, daemon=True).start()
     losses = torch.zeros(steps, 3, device="cuda")
     for s in range(steps):
         ii = idx[s * B:(s + 1) * B]
