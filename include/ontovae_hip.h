@@ -445,7 +445,9 @@ int ontovae_fdr_bh(const double* pvals, int32_t n, int32_t nsets, double* qvals,
  * hipMalloc).  The `raw` values and NaN flags that ontovae_fdr_bh keeps in the caller's workspace live in a file-scope
  * device array of the library instead (2 MiB + 16 KiB per GPU, held until the process ends).  Limits: n * nsets <= 262144
  * p-values and nsets <= 4096; larger inputs return ONTOVAE_EINVAL (use ontovae_fdr_bh).  Results are bit-identical to
- * ontovae_fdr_bh.  All calls on one GPU share the array: calls that overlap on one GPU (two streams) race. */
+ * ontovae_fdr_bh.  All calls on one GPU share the array: calls that overlap on one GPU (two streams) race.  The first call
+ * on a device resolves the array's address (hipGetSymbolAddress, under a mutex): make one call per device outside any graph
+ * capture.  qvals must not alias pvals, here and in ontovae_fdr_bh (ONTOVAE_EINVAL). */
 int ontovae_fdr_bh_static(const double* pvals, int32_t n, int32_t nsets, double* qvals, void* stream);
 int ontovae_to_feature_major(const float* src, int64_t src_ld, int32_t B, int32_t F, float* dst,
                              int64_t dst_ld, void* stream);
@@ -498,7 +500,9 @@ int ontovae_vae_train_step(const ontovae_vae_ctx_t* ctx, const float* x, const i
                            uint64_t rng_offset, float kl_coeff, const ontovae_adamw_t* opt, int32_t apply_update, float* loss_out,
                            void* stream);
 /* VAE.forward (vae_model.py:979-990) / get_embedding (:965-977) and, with loss_out != NULL, one body of val_round
- * (:1061-1065).  Outputs (any may be NULL): recon [B, G], mu, log_var, z [B, Z], sample-major; loss_out: device float[3]. */
+ * (:1061-1065).  Outputs (any may be NULL): recon [B, G], mu, log_var, z [B, Z], sample-major; loss_out: device float[3].
+ * With recon == NULL and loss_out == NULL only the encoder and the reparameterisation run (Encoder.forward, modules.py:74-84:
+ * the decoder's BatchNorm buffers do not move). */
 int ontovae_vae_forward(const ontovae_vae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
                         uint64_t rng_offset, int32_t train, float kl_coeff, float* recon, float* mu, float* log_var, float* z_out,
                         float* loss_out, void* stream);

@@ -279,7 +279,9 @@ static int ov_vae_block_fwd(OvVaeStep& s, const OvVaeLayer& l, const float* prev
 }
 
 // encoder + heads + reparameterisation + decoder; leaves recon (with bias) in ws.rec, mu / log_var in ws.mulv, z in ws.z
-static int ov_vae_forward_core(OvVaeStep& s, const float* eps, int train, int write_kl, int* nkl) {
+// encoder_only: stop after the reparameterisation (Encoder.forward / get_embedding, modules.py:74-84, vae_model.py:970-981: the
+// reference runs no decoder there, so the decoder's BatchNorm buffers must not move in train mode)
+static int ov_vae_forward_core(OvVaeStep& s, const float* eps, int train, int write_kl, int* nkl, bool encoder_only = false) {
     const ontovae_vae_ctx_t* c = s.c;
     const OvVaeNet& n = s.n;
     int rc;
@@ -308,6 +310,7 @@ static int ov_vae_forward_core(OvVaeStep& s, const float* eps, int train, int wr
         OV_LAUNCH_CHECK();
         if (nkl) *nkl = blocks;
     }
+    if (encoder_only) return ONTOVAE_OK;
     prev = s.ws.z;
     for (int i = 0; i < n.nd; ++i) {
         OvVaeLayer l = n.dec[i];
@@ -464,7 +467,7 @@ extern "C" int ontovae_vae_forward(const ontovae_vae_ctx_t* ctx, const float* x,
     s.rng_off = rng_offset;
     const OvVaeNet& n = s.n;
     int nkl = 0, nrec = 0;
-    if ((rc = ov_vae_forward_core(s, eps, train ? 1 : 0, loss_out ? 1 : 0, &nkl))) return rc;
+    if ((rc = ov_vae_forward_core(s, eps, train ? 1 : 0, loss_out ? 1 : 0, &nkl, !recon && !loss_out))) return rc;
     OvStep t{};
     t.B = B; t.ldb = s.ldb; t.st = s.st;
     if (recon && (rc = ov_transpose_out(t, s.ws.rec, n.G, recon, n.G))) return rc;

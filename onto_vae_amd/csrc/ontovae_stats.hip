@@ -589,6 +589,7 @@ extern "C" int ontovae_fdr_bh(const double* pvals, int32_t n, int32_t nsets, dou
     if (n < 0 || nsets < 0) { ontovae_set_error("fdr_bh: n = %d, nsets = %d", n, nsets); return ONTOVAE_EINVAL; }
     if (n == 0 || nsets == 0) return ONTOVAE_OK;
     if (!pvals || !qvals) { ontovae_set_error("fdr_bh: NULL argument"); return ONTOVAE_EINVAL; }
+    if (pvals == qvals) { ontovae_set_error("fdr_bh: qvals must not alias pvals (the second kernel reads p-values that other blocks' q-values would overwrite)"); return ONTOVAE_EINVAL; }
     if (!workspace || workspace_bytes < ontovae_fdr_workspace_bytes(n, nsets) || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
         ontovae_set_error("fdr_bh: workspace of %lld bytes, 256-byte aligned, required (ontovae_fdr_workspace_bytes)",
                           (long long)ontovae_fdr_workspace_bytes(n, nsets));
@@ -643,6 +644,7 @@ extern "C" int ontovae_fdr_bh_static(const double* pvals, int32_t n, int32_t nse
     if (n < 0 || nsets < 0) { ontovae_set_error("fdr_bh_static: n = %d, nsets = %d", n, nsets); return ONTOVAE_EINVAL; }
     if (n == 0 || nsets == 0) return ONTOVAE_OK;
     if (!pvals || !qvals) { ontovae_set_error("fdr_bh_static: NULL argument"); return ONTOVAE_EINVAL; }
+    if (pvals == qvals) { ontovae_set_error("fdr_bh_static: qvals must not alias pvals"); return ONTOVAE_EINVAL; }
     if ((int64_t)n * nsets > OV_FDR_STATIC_PVALS || nsets > OV_FDR_STATIC_SETS) {
         ontovae_set_error("fdr_bh_static: %d sets of %d p-values exceed the static scratch (n * nsets <= %d, nsets <= %d); "
                           "use ontovae_fdr_bh with a workspace", nsets, n, OV_FDR_STATIC_PVALS, OV_FDR_STATIC_SETS);

@@ -43,11 +43,21 @@ class FusedAdamW:
 
     def state_dict(self):
         e = self.engine
+        # the flat moments follow the packed order of the plan (ontovae_plan_row_k), which changed between library ABIs:
+        # the ABI version travels with them and load_state_dict refuses a state written in another order
+        from ._lib import ABI_VERSION
         return {"state": {"step": self.step_count, "exp_avg": e.M.detach().clone(), "exp_avg_sq": e.V.detach().clone()},
-                "param_groups": [dict(g) for g in self.param_groups], "format": "onto_vae_amd.flat.v1"}
+                "param_groups": [dict(g) for g in self.param_groups], "format": "onto_vae_amd.flat.v2", "packed_order_abi": ABI_VERSION}
 
     def load_state_dict(self, sd):
+        from ._lib import ABI_VERSION
         e = self.engine
+        if sd.get("format") != "onto_vae_amd.flat.v2" or int(sd.get("packed_order_abi", -1)) != ABI_VERSION:
+            raise ValueError(f"optimizer state in format {sd.get('format')!r} / packed order of ABI {sd.get('packed_order_abi')!r}: this "
+                             f"library packs the decoder in the order of ABI {ABI_VERSION}; its flat moments cannot be taken over "
+                             "(the model's state_dict is dense and loads in any version)")
+        if tuple(sd["state"]["exp_avg"].shape) != tuple(e.P.shape):
+            raise ValueError("optimizer state belongs to a model of another size")
         e.ensure_opt_state()
         e.M.copy_(sd["state"]["exp_avg"]); e.V.copy_(sd["state"]["exp_avg_sq"])
         self.step_count = int(sd["state"]["step"])

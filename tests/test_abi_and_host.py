@@ -101,3 +101,26 @@ def test_errors_follow_the_reference():
             model.forward(torch.zeros(4, 12))
         with pytest.raises(OntoVAEHipError):
             model.get_pathway_activities(onto, "d")
+
+
+def test_optimizer_state_carries_its_packed_order():
+    """FusedAdamW's flat moments follow the plan's packed order, which changed between library ABIs (row_k, ABI 2 -> 7): the
+    state names the ABI it was written under and another order is refused instead of being loaded scrambled."""
+    from onto_vae_amd._lib import ABI_VERSION
+    from onto_vae_amd.synthetic import StubOntobj, synthetic_masks
+    from onto_vae_amd.vae_model import FusedAdamW, OntoVAE
+    masks = synthetic_masks([3, 4], 12, 1)
+    model = OntoVAE(StubOntobj(masks, data={"d": np.zeros((3, 12))}), "d")
+    opt = FusedAdamW(model, lr=1e-3)
+    opt.step_count = 5
+    model._engine.M.fill_(0.25)
+    sd = opt.state_dict()
+    assert sd["format"] == "onto_vae_amd.flat.v2" and sd["packed_order_abi"] == ABI_VERSION
+    opt2 = FusedAdamW(model, lr=1e-4)
+    model._engine.M.zero_()
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 5 and float(model._engine.M.min()) == 0.25 and opt2.param_groups[0]["lr"] == 1e-3
+    for bad in (dict(sd, format="onto_vae_amd.flat.v1"), dict(sd, packed_order_abi=ABI_VERSION - 1),
+                {k: v for k, v in sd.items() if k != "packed_order_abi"}):
+        with pytest.raises(ValueError, match="packed order"):
+            opt2.load_state_dict(bad)

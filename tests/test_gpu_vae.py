@@ -280,3 +280,30 @@ def test_vae_rejects_bad_arguments():
         m(torch.zeros(1, 30))
     with pytest.raises(ValueError):
         VAE(np.zeros((4, 30), np.float32), [8] * 9, [8], 4)
+
+
+def test_vae_get_embedding_leaves_the_decoder_alone():
+    """VAE.get_embedding and Encoder.forward run the encoder only (vae_model.py:970-981, modules.py:74-84): in train mode the
+    encoder's BatchNorm buffers move, the decoder's running_mean / running_var / num_batches_tracked must not; the values equal
+    those of the full forward."""
+    fx = fixture("vae_deep")
+    m = build(fx)
+    m.train()
+    x = torch.as_tensor(fx["x/0"])
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    feed(m, fx["eps/0"])
+    z = m.get_embedding(x)
+    mu, lv = m.encoder(x)
+    after = m.state_dict()
+    for k, v in before.items():
+        if k.startswith("decoder."):
+            assert torch.equal(after[k], v), k
+    assert int(after["encoder.encoder.0.1.num_batches_tracked"]) == int(before["encoder.encoder.0.1.num_batches_tracked"]) + 2
+    assert not torch.equal(after["encoder.encoder.0.1.running_mean"], before["encoder.encoder.0.1.running_mean"])
+    m2 = build(fx)
+    m2.train()
+    feed(m2, fx["eps/0"])
+    _, mu2, lv2 = m2.forward(x)
+    assert torch.equal(mu2, mu) or torch.allclose(mu2, mu, rtol=1e-5, atol=1e-6)
+    want_z = mu2 + torch.as_tensor(fx["eps/0"]).cuda() * torch.exp(0.5 * lv2)
+    assert torch.allclose(z, want_z, rtol=1e-5, atol=1e-6)
