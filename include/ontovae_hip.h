@@ -167,7 +167,12 @@ int ontovae_plan_gsell_export(const ontovae_plan_t* plan, int32_t* gene, int32_t
  * which = 1: panel tiles ([ceil(C / 32) * 32 * 4]; rows are panel nodes, lists the gene part of their CSC columns, unused: row C);
  * which = 2: term tiles ([ceil((C - L) / 32) * 32 * 4]; rows are the term layers' output nodes [0, C - L), lists their CSR rows,
  *            unused: row C - L): what the weight-gradient workgroups of the term layers read first.
- * Optional in the context (NULL: every workgroup ranks its tile's rows itself). */
+ * which = 3: term-panel tiles ([4 + ceil((C / nu) / 32) * 32 * 4]: out[0] = 1 if present, else 0 and nothing follows; out[1] = the
+ *            largest sum of list lengths over the tiles; the records start at out + 4): rows are the TERMS of the panel (record.z = the term's first node nu * t, C if unused), the list is
+ *            the gene part of that node's CSC column, which the term's nu nodes share (the gene mask is expanded along its
+ *            columns, modules.py:275); the packed positions of node nu * t + e start at record.w + e * length.  The backward
+ *            gene kernel then gathers a gene's row once for the nu nodes.
+ * Optional in the context (NULL: every workgroup ranks its tile's rows itself; tpanel_tiles NULL: one lane group per node). */
 int ontovae_plan_tile_info(const ontovae_plan_t* plan, int32_t which, int32_t* out);
 
 typedef struct ontovae_layout {
@@ -226,6 +231,8 @@ typedef struct ontovae_ctx {
     const int32_t* gene_tiles; /* device, ontovae_plan_tile_info(plan, 0), or NULL */
     const int32_t* panel_tiles;/* device, ontovae_plan_tile_info(plan, 1), or NULL */
     const int32_t* term_tiles; /* device, ontovae_plan_tile_info(plan, 2), or NULL */
+    const int32_t* tpanel_tiles;/* device, the RECORDS of ontovae_plan_tile_info(plan, 3) (out + 4), or NULL */
+    int32_t tpanel_max_entries; /* out[1] of ontovae_plan_tile_info(plan, 3): the largest sum of list lengths of a term-panel tile */
 } ontovae_ctx_t;
 
 #define ONTOVAE_FLAG_LEVEL_LAUNCHES 1u  /* one launch per decoder level instead of the LDS-fused chain */

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ONTOVAE_HIP_LIB") or os.path.join(HERE, "libontovae_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -52,7 +52,8 @@ class Ctx(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_batch", C.c_int32), ("max_train_batch", C.c_int32),
                 ("drop", C.c_float), ("z_drop", C.c_float), ("seed", C.c_uint64), ("flags", C.c_uint32),
                 ("sell_fwd", Sell), ("sell_bwd", Sell), ("bf16_ws", C.c_void_p), ("bf16_ws_bytes", C.c_int64),
-                ("gsell", GSell), ("gene_tiles", C.c_void_p), ("panel_tiles", C.c_void_p), ("term_tiles", C.c_void_p)]
+                ("gsell", GSell), ("gene_tiles", C.c_void_p), ("panel_tiles", C.c_void_p), ("term_tiles", C.c_void_p),
+                ("tpanel_tiles", C.c_void_p), ("tpanel_max_entries", C.c_int32)]
 
 
 VAE_MAXL = 8

@@ -4,7 +4,7 @@
 
 #include "../../include/ontovae_hip.h"
 
-#define ONTOVAE_ABI_VERSION 7
+#define ONTOVAE_ABI_VERSION 8
 
 #ifdef __cplusplus
 extern "C++" {

@@ -1780,6 +1780,205 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
+// The same on tiles of 32 TERMS (ontovae_plan_tile_info which = 3): the NU neurons of a term have the same genes below them,
+// so a lane group takes a term, gathers each gene's D row ONCE and uses it for the NU nodes: NU data-gradient accumulators,
+// NU weight-gradient dots.  A third of the gathers of ov_bwd_gene_cb_kernel at nu = 3 (the gathers, 128 B per link and block
+// through the L2, are what that kernel is made of).  Entry e of node nu t + j has the packed position kb + j len + e.
+template <int NU>
+__device__ __forceinline__ void ov_gather_term_wgrad(f32x4 (&acc)[NU], int k0, int len, const int32_t* __restrict__ rowidx,
+                                                     const float* __restrict__ vals, const float* __restrict__ srccol, int ldb, int lane,
+                                                     const f32x4 (&aseg)[NU], float* __restrict__ part, int kb) {
+    const int s = lane & 7;
+    int maxlen = len;                    // wave maximum of len
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    auto fetch = [&](int e, int& r, float (&w)[NU], int& k) {
+        const int ee = max(min(e, len - 1), 0);
+        r = len > 0 ? rowidx[k0 + ee] : 0;
+        k = -1;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) w[j] = 0.f;
+        if (e < len) {
+            k = kb + e;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) w[j] = vals[k + j * len];
+        }
+    };
+    int cur_r, nxt_r = 0, cur_k, nxt_k = -1;
+    float cur_w[NU], nxt_w[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) nxt_w[j] = 0.f;
+    fetch(s, cur_r, cur_w, cur_k);
+    for (int b0 = 0; b0 < maxlen; b0 += 8) {
+        if (b0 + 8 < maxlen) fetch(b0 + 8 + s, nxt_r, nxt_w, nxt_k);
+        f32x4 v[8];
+#define OV_GT_STEP(I) v[I] = *reinterpret_cast<const f32x4*>(srccol + (int64_t)ov_grp_bcast<I>(cur_r) * ldb);
+        OV_GT_STEP(0) OV_GT_STEP(1) OV_GT_STEP(2) OV_GT_STEP(3) OV_GT_STEP(4) OV_GT_STEP(5) OV_GT_STEP(6) OV_GT_STEP(7)
+#undef OV_GT_STEP
+        float mine[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) mine[j] = 0.f;
+#define OV_GT_USE(I)                                                                                      \
+        {                                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < NU; ++j) {                                              \
+                const float w = ov_grp_bcast<I>(cur_w[j]);                                                \
+                acc[j].x += w * v[I].x; acc[j].y += w * v[I].y;                                           \
+                acc[j].z += w * v[I].z; acc[j].w += w * v[I].w;                                           \
+                float t = v[I].x * aseg[j].x;                                                             \
+                t += v[I].y * aseg[j].y;                                                                  \
+                t += v[I].z * aseg[j].z;                                                                  \
+                t += v[I].w * aseg[j].w;                                                                  \
+                t = ov_group_sum<3>(t);                                                                   \
+                mine[j] = s == I ? t : mine[j];                                                           \
+            }                                                                                             \
+        }
+        OV_GT_USE(0) OV_GT_USE(1) OV_GT_USE(2) OV_GT_USE(3) OV_GT_USE(4) OV_GT_USE(5) OV_GT_USE(6) OV_GT_USE(7)
+#undef OV_GT_USE
+        if (cur_k >= 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) part[cur_k + j * len] = mine[j];
+        }
+        cur_r = nxt_r; cur_k = nxt_k;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) cur_w[j] = nxt_w[j];
+    }
+}
+
+template <int NU, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ov_bwd_gene_term_kernel(
+        const int32_t* __restrict__ csc_row, const float* __restrict__ vals, float* __restrict__ d, float* __restrict__ dblk, int C,
+        int ldb, int ncb, int ntiles, const float* __restrict__ act, float* __restrict__ wpart, int64_t nnz,
+        const int4* __restrict__ tiles) {
+    const OvCbMap map = ov_cb_map(blockIdx.x, ncb, ntiles);
+    if (map.tile >= ntiles) return;
+    const int lane = ov_lane();
+    const int col0 = map.cb * 32, s4 = 4 * (lane & 7);
+    const int4 ti = tiles[map.tile * 32 + (threadIdx.x >> 3)];
+    const int k0 = ti.x, len = ti.y, node = ti.z, kb = ti.w;
+    f32x4 acc[NU], aseg[NU];
+    const int n0 = min(node, C - NU);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        aseg[j] = *reinterpret_cast<const f32x4*>(act + (int64_t)(n0 + j) * ldb + col0 + s4);
+    }
+    ov_gather_term_wgrad<NU>(acc, k0, len, csc_row, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz, kb);
+    if (node < C) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            *reinterpret_cast<f32x4*>(d + (int64_t)(node + j) * ldb + col0 + s4) = acc[j];
+            if (dblk) *reinterpret_cast<f32x4*>(dblk + ((int64_t)(map.cb * 8 + (lane & 7)) * C + node + j) * 4) = acc[j];
+        }
+    }
+}
+
+// The term-tile kernel with the tile's lists in LDS and ALL column blocks of its XCD in one workgroup.  Counters of the two
+// kernels above at 8192 columns (profiles/r03/bwd_gene_counters.txt): waves parked at s_waitcnt two thirds of the time, L1 miss
+// queue full (TCP_PENDING_STALL), L2 hit rate 55-72 % although a block's D rows (2.5 MB) fit the XCD's 4 MB L2 -- every block
+// also streams the tile lists and weights (3.8 MB of index + weight per block), the partials and the panel slice through it.
+// Here a workgroup copies its tile's lists once into LDS as {gene row, NU weights} records and walks the blocks xcd, xcd + 8,
+// xcd + 16, ... with them: per block the L2 sees the D gathers, one panel piece per node and the partials, nothing else, and the
+// index / weight fetches and their ds_swizzle broadcasts leave the inner loop (a group's 8 lanes read one record: a broadcast).
+template <int NU>
+struct OvTermEnt { int32_t row; float w[NU]; };
+template <int NU, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ov_bwd_gene_term_lds_kernel(
+        const int32_t* __restrict__ csc_row, const float* __restrict__ vals, float* __restrict__ d, float* __restrict__ dblk, int C,
+        int ldb, int ncb, int ntiles, const float* __restrict__ act, float* __restrict__ wpart, int64_t nnz,
+        const int4* __restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ov_tl_raw[];
+    __shared__ int sh_off[33];
+    OvTermEnt<NU>* ent = reinterpret_cast<OvTermEnt<NU>*>(ov_tl_raw);
+    // workgroup -> (first column block, tile): as ov_cb_map, but a workgroup keeps its tile for every block of its XCD
+    const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
+    int cb0, cbstep, tile;
+    if (ncb <= 8) { const int xpc = 8 / ncb; cb0 = xcd % ncb; tile = q * xpc + xcd / ncb; cbstep = ncb; }
+    else { cb0 = xcd; tile = q; cbstep = 8; }
+    if (tile >= ntiles) return;
+    const int lane = ov_lane(), grp = threadIdx.x >> 3, s = lane & 7, s4 = 4 * s;
+    const int4 ti = tiles[tile * 32 + grp];
+    const int k0 = ti.x, len = ti.y, node = ti.z, kb = ti.w;
+    if (s == 0) sh_off[grp] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int g = 0; g < 32; ++g) { const int l = sh_off[g]; sh_off[g] = run; run += l; }
+        sh_off[32] = run;
+    }
+    __syncthreads();
+    const int off = sh_off[grp];
+    for (int e = s; e < len; e += 8) {
+        OvTermEnt<NU> t;
+        t.row = csc_row[k0 + e];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) t.w[j] = vals[kb + j * len + e];
+        ent[off + e] = t;
+    }
+    __syncthreads();
+    int maxlen = len;                    // wave maximum of len
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    const int n0 = min(node, C - NU);
+    const OvTermEnt<NU>* mine_ent = ent + off;
+    for (int cb = cb0; cb < ncb; cb += cbstep) {
+        const int col0 = cb * 32;
+        const float* srccol = d + col0 + s4;
+        float* part = wpart + (int64_t)cb * nnz;
+        f32x4 acc[NU], aseg[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            aseg[j] = *reinterpret_cast<const f32x4*>(act + (int64_t)(n0 + j) * ldb + col0 + s4);
+        }
+        for (int b0 = 0; b0 < maxlen; b0 += 8) {
+            f32x4 v[8];
+            OvTermEnt<NU> en[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = b0 + i;
+                en[i] = mine_ent[max(min(e, len - 1), 0)];          // an empty list reads record 0 of the tile's area (or stale LDS): weight forced to 0, row clamped
+                if (len <= 0) en[i].row = 0;
+                if (e >= len) {
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) en[i].w[j] = 0.f;
+                }
+                v[i] = *reinterpret_cast<const f32x4*>(srccol + (int64_t)en[i].row * ldb);
+            }
+            float mine[NU];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) mine[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    const float w = en[i].w[j];
+                    acc[j].x += w * v[i].x; acc[j].y += w * v[i].y;
+                    acc[j].z += w * v[i].z; acc[j].w += w * v[i].w;
+                    float t = v[i].x * aseg[j].x;
+                    t += v[i].y * aseg[j].y;
+                    t += v[i].z * aseg[j].z;
+                    t += v[i].w * aseg[j].w;
+                    t = ov_group_sum<3>(t);
+                    mine[j] = s == i ? t : mine[j];
+                }
+            }
+            if (b0 + s < len) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) part[kb + j * len + b0 + s] = mine[j];
+            }
+        }
+        if (node < C) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                *reinterpret_cast<f32x4*>(d + (int64_t)(node + j) * ldb + col0 + s4) = acc[j];
+                if (dblk) *reinterpret_cast<f32x4*>(dblk + ((int64_t)(cb * 8 + s) * C + node + j) * 4) = acc[j];
+            }
+        }
+    }
+}
+
 // Backward data, one wave per (panel node of the level, batch chunk), CSC gather:
 //   D[p, :] = sum_q vals[csc_k[q]] * D[csc_row[q], :]
 // csc_split != NULL: the term part of the lists only, added to what D[p, :] holds (the gene part, from ov_bwd_gene_cb_kernel)
@@ -3022,12 +3221,42 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
         // columns against 24.7 with 4); once every XCD works through many blocks, fewer waves leave more of its L2 to each
         // (1024 columns: 170 us with 4 against 176 with 5; 8192: 1.40 ms with 3, 1.43 with 4, 1.52 with 5)
         const int wpe = s.ldb >= 4096 ? 3 : (s.ldb >= 1024 ? 4 : 5);
+        // one lane group per TERM where the plan provides term tiles and the weight gradient rides here (the usual case):
+        // a gene's D row is gathered once for the term's nu nodes
+        const int tp_mode = OV_DBG((c->flags >> 26) & 3);       // measurement builds: 1 = per-node kernel even so
+        // Which form (measured, GO-BP, us at 1024 / 2048 / 4096 / 8192 columns; per-node kernel 164 / 316 / 657 / 1263):
+        //   term tiles, lists in LDS, a workgroup walks all blocks of its XCD : 158 / 291 / 680 / 1386  (the tiles drift apart over
+        //                                                                      many blocks and several blocks' D rows share the L2)
+        //   term tiles, block-major as the per-node kernel                   :   - /   - / 612 / 1183
+        // below 512 columns the per-node kernel stays (4 x more workgroups for the few blocks there are: 20.6 us at 128 columns).
+        const size_t tl_lds = (size_t)c->tpanel_max_entries * (1 + d.nu) * 4;
+        const bool term_ok = c->tpanel_tiles && s.gw_part && d.nu >= 1 && d.nu <= 3 && tp_mode != 1;
+        if (term_ok && tp_mode != 2 && c->tpanel_max_entries > 0 && tl_lds <= 48 * 1024 && ((s.ldb >= 512 && s.ldb < 4096) || tp_mode == 3)) {
+            const int tt = (d.C / d.nu + 31) / 32;
+            const int4* tl = reinterpret_cast<const int4*>(c->tpanel_tiles);
+            const int grid = ncb <= 8 ? ov_cb_grid(ncb, tt) : 8 * tt;
+#define OV_BG_L(N, W) do { if ((rc = ov_set_lds(ov_bwd_gene_term_lds_kernel<N, W>, tl_lds))) return rc;                          \
+                           hipLaunchKernelGGL((ov_bwd_gene_term_lds_kernel<N, W>), dim3(grid), dim3(256), tl_lds, s.st, c->csc_row, vals, s.ws.d, blk, d.C, \
+                           s.ldb, ncb, tt, s.ws.act, s.gw_part, (int64_t)d.nnz, tl); } while (0)
+            if (d.nu == 1) OV_BG_L(1, 4); else if (d.nu == 2) OV_BG_L(2, 4); else OV_BG_L(3, 3);
+#undef OV_BG_L
+            OV_LAUNCH_CHECK();
+        } else if (term_ok && (s.ldb >= 4096 || tp_mode == 2)) {
+            const int tt = (d.C / d.nu + 31) / 32;
+            const int4* tl = reinterpret_cast<const int4*>(c->tpanel_tiles);
+#define OV_BG_T(N, W) hipLaunchKernelGGL((ov_bwd_gene_term_kernel<N, W>), dim3(ov_cb_grid(ncb, tt)), dim3(256), 0, s.st, c->csc_row, vals, s.ws.d, blk, d.C, \
+                           s.ldb, ncb, tt, s.ws.act, s.gw_part, (int64_t)d.nnz, tl)
+            if (d.nu == 1) OV_BG_T(1, 4); else if (d.nu == 2) OV_BG_T(2, 4); else OV_BG_T(3, 3);      // waves per SIMD the registers allow without spills
+#undef OV_BG_T
+            OV_LAUNCH_CHECK();
+        } else {
 #define OV_BG_CB(W) hipLaunchKernelGGL(ov_bwd_gene_cb_kernel<W>, dim3(ov_cb_grid(ncb, ntiles)), dim3(256), 0, s.st, c->cscptr, c->csc_split, c->csc_row, \
                            c->csc_k, vals, s.ws.d, blk, d.C, s.ldb, ncb, ntiles, s.ws.act, s.gw_part, (int64_t)d.nnz, \
                            reinterpret_cast<const int4*>(c->panel_tiles))
         if (wpe == 3) OV_BG_CB(3); else if (wpe == 4) OV_BG_CB(4); else OV_BG_CB(5);
 #undef OV_BG_CB
         OV_LAUNCH_CHECK();
+        }
     } else {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
         dim3 grid((d.C + 3) / 4, s.nchunk);

@@ -51,7 +51,7 @@ struct ontovae_plan {
         std::vector<uint16_t> col;
     } gsell;
     // tiles of 32 rows as the column-block gene kernels take them (ontovae_plan_tile_info), 4 ints per slot
-    std::vector<int32_t> gene_tiles, panel_tiles, term_tiles;
+    std::vector<int32_t> gene_tiles, panel_tiles, term_tiles, tpanel_tiles;
 };
 
 // The column-block gene kernels give every lane group of a 32-row tile one row, longest list first, so that the 8 groups
@@ -61,7 +61,12 @@ struct ontovae_plan {
 //   gene tiles : rows = genes g (record.z = g, G for an unused slot), lists = CSR rows C + g, record.w = 0
 //   panel tiles: rows = panel nodes p (record.z = p, C if unused), lists = gene part of CSC column p
 //   term tiles : rows = the term layers' output nodes n in [0, C - L) (record.z = n, C - L if unused), lists = CSR rows n
-static void build_tiles(ontovae_plan* p) {
+//   term-panel tiles: rows = TERMS t of the panel (record.z = first node nu * t, C if unused), list = gene part of CSC column
+//                nu * t.  The nu neurons of a term have the same genes below them (the gene mask is expanded along its columns,
+//                modules.py:275), in the same order, and their links sit nu runs of `len` apart in the packed order
+//                (record.w, + len, + 2 len, ...): the backward gene kernel gathers a gene's D row ONCE for the nu nodes.
+//                Left empty when a structure does not have that property (then the per-node tiles are used).
+static void build_tiles(ontovae_plan* p, int32_t nu) {
     const int32_t C = p->dims.C, G = (int32_t)(p->rowptr.size() - 1) - C;
     auto make = [&](int32_t n, int32_t unused, auto k0_of, auto len_of, auto kb_of, std::vector<int32_t>& out) {
         const int32_t ntiles = (n + 31) / 32;
@@ -95,6 +100,27 @@ static void build_tiles(ontovae_plan* p) {
     const int32_t nterm = p->level_begin.empty() ? 0 : p->level_begin[0];      // nodes [0, C - L): levels 1 .. K-1
     make(nterm, nterm, [&](int32_t n) { return p->rowptr[n]; }, [&](int32_t n) { return p->rowptr[n + 1] - p->rowptr[n]; },
          [&](int32_t) { return 0; }, p->term_tiles);
+    p->tpanel_tiles.clear();
+    if (nu >= 1 && nu <= 4 && C % nu == 0) {
+        const int32_t T = C / nu;
+        bool ok = true;
+        for (int32_t t = 0; t < T && ok; ++t) {
+            const int32_t c0 = t * nu, k0 = split(c0), len = p->cscptr[c0 + 1] - k0;
+            for (int32_t e = 1; e < nu && ok; ++e) {
+                const int32_t ke = split(c0 + e);
+                ok = p->cscptr[c0 + e + 1] - ke == len && std::equal(p->csc_row.begin() + k0, p->csc_row.begin() + k0 + len, p->csc_row.begin() + ke) &&
+                     (len == 0 || p->csc_k[ke] == p->csc_k[k0] + e * len);
+            }
+            for (int32_t j = 1; j < len && ok; ++j) ok = p->csc_k[k0 + j] == p->csc_k[k0] + j;
+        }
+        if (ok) {
+            std::vector<int32_t> tmp;
+            make(T, T, [&](int32_t t) { return split(t * nu); }, [&](int32_t t) { return p->cscptr[t * nu + 1] - split(t * nu); },
+                 [&](int32_t t) { return p->csc_k[split(t * nu)]; }, tmp);
+            for (size_t i = 0; i + 3 < tmp.size(); i += 4) tmp[i + 2] = tmp[i + 2] >= T ? C : tmp[i + 2] * nu;      // first node of the term
+            p->tpanel_tiles.swap(tmp);
+        }
+    }
 }
 
 // Gene layer, one gene per lane.  List lengths run from 3 to 60 links at GO-BP scale: slices of 64 consecutive genes would be
@@ -397,7 +423,7 @@ static int build(int32_t K, const int32_t* rows, const int32_t* cols, int32_t nu
     build_sell(p, 0);
     build_sell(p, 1);
     build_gsell(p);
-    build_tiles(p);
+    build_tiles(p, nu);
     p->dims.G = (int32_t)G;
     p->dims.T = (int32_t)T;
     p->dims.K = K;
@@ -530,8 +556,19 @@ extern "C" int ontovae_plan_gsell_export(const ontovae_plan_t* plan, int32_t* ge
 }
 
 extern "C" int ontovae_plan_tile_info(const ontovae_plan_t* plan, int32_t which, int32_t* out) {
-    if (!plan || !out || which < 0 || which > 2) return ONTOVAE_EINVAL;
-    const std::vector<int32_t>& v = which == 0 ? plan->gene_tiles : (which == 1 ? plan->panel_tiles : plan->term_tiles);
+    if (!plan || !out || which < 0 || which > 3) return ONTOVAE_EINVAL;
+    const std::vector<int32_t>& v = which == 0 ? plan->gene_tiles : (which == 1 ? plan->panel_tiles : (which == 2 ? plan->term_tiles : plan->tpanel_tiles));
+    if (which == 3) {          // out[0] = 1 if the structure has term-panel tiles, then the records
+        out[0] = v.empty() ? 0 : 1;
+        out[1] = 0;                    // the largest sum of list lengths over the tiles (entries a workgroup stages in LDS)
+        for (size_t t = 0; t + 127 < v.size(); t += 128) {
+            int32_t sum = 0;
+            for (int s_ = 0; s_ < 32; ++s_) sum += v[t + (size_t)s_ * 4 + 1];
+            out[1] = std::max(out[1], sum);
+        }
+        if (!v.empty()) std::memcpy(out + 4, v.data(), sizeof(int32_t) * v.size());
+        return ONTOVAE_OK;
+    }
     if (!v.empty()) std::memcpy(out, v.data(), sizeof(int32_t) * v.size());
     return ONTOVAE_OK;
 }

@@ -164,7 +164,8 @@ class Engine:
         self._gsell["w"] = torch.zeros(max(gs["n_quads"], 1) * 256, dtype=torch.float32, device=dev)
         self._idx = dict(rowptr=t(p.rowptr), colidx=t(p.colidx), cscptr=t(p.cscptr), csc_row=t(p.csc_row),
                          csc_k=t(p.csc_k), csc_split=t(p.csc_split), row_k=t(p.row_k), er=t(p.entry_row), ec=t(p.entry_col),
-                         gene_tiles=t(p.gene_tiles), panel_tiles=t(p.panel_tiles), term_tiles=t(p.term_tiles))
+                         gene_tiles=t(p.gene_tiles), panel_tiles=t(p.panel_tiles), term_tiles=t(p.term_tiles),
+                         tpanel_tiles=t(p.tpanel_tiles) if p.tpanel_tiles is not None else None)
         self._ctx = None
 
     def to(self, device):
@@ -234,6 +235,8 @@ class Engine:
             c.csc_split = _ptr(i["csc_split"])
             c.row_k = _ptr(i["row_k"])
             c.gene_tiles, c.panel_tiles, c.term_tiles = _ptr(i["gene_tiles"]), _ptr(i["panel_tiles"]), _ptr(i["term_tiles"])
+            c.tpanel_tiles = _ptr(i["tpanel_tiles"])
+            c.tpanel_max_entries = self.plan.tpanel_max_entries
             c.level_begin = self.plan.level_begin.ctypes.data_as(_lib.c_i32p)
             c.level_end = self.plan.level_end.ctypes.data_as(_lib.c_i32p)
             for name, sd, dev in (("sell_fwd", self.plan.sell[0], self._sell[0]), ("sell_bwd", self.plan.sell[1], self._sell[1])):

@@ -85,6 +85,11 @@ class MaskPlan:
         _lib.check(L.ontovae_plan_tile_info(handle, 1, _i32p(self.panel_tiles)), "panel tiles")
         self.term_tiles = np.zeros(max((self.C - self.L + 31) // 32 * 32 * 4, 4), dtype=np.int32)
         _lib.check(L.ontovae_plan_tile_info(handle, 2, _i32p(self.term_tiles)), "term tiles")
+        # 32-term tiles of the backward gene kernel: one lane group per term, the nu nodes share the gathers (None: not available)
+        tp = np.zeros(4 + (self.C // max(self.nu, 1) + 31) // 32 * 32 * 4, dtype=np.int32)
+        _lib.check(L.ontovae_plan_tile_info(handle, 3, _i32p(tp)), "term-panel tiles")
+        self.tpanel_tiles = tp[4:].copy() if tp[0] == 1 else None
+        self.tpanel_max_entries = int(tp[1]) if tp[0] == 1 else 0
         self.entry_layer = np.zeros(n, dtype=np.int32)
         self.entry_row = np.zeros(n, dtype=np.int32)
         self.entry_col = np.zeros(n, dtype=np.int32)

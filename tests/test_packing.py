@@ -108,6 +108,27 @@ def check_plan(masks, nu):
             assert rec[0] == plan.csc_split[p_] and rec[1] == plan.cscptr[p_ + 1] - plan.csc_split[p_]
             if rec[1] > 0:
                 assert rec[3] == plan.csc_k[rec[0]]
+    # 32-term tiles of the backward gene kernel: every term once, longest list first; the term's nu nodes share the gene list
+    # of its first node and their links sit `len` apart in the packed order
+    nu = plan.nu
+    if nu <= 4:
+        assert plan.tpanel_tiles is not None
+        T_ = C // nu
+        tp = plan.tpanel_tiles.reshape(-1, 32, 4)
+        assert tp.shape[0] == (T_ + 31) // 32
+        for t, rec in enumerate(tp):
+            nodes = rec[:, 2]
+            assert sorted(nodes[nodes != C].tolist()) == [nu * r for r in range(t * 32, t * 32 + 32) if r < T_]
+            assert np.all(np.diff(rec[:, 1]) <= 0) and np.all(rec[nodes == C, 1] == 0)
+        for k0, ln, node, kb in tp.reshape(-1, 4):
+            if node == C:
+                continue
+            assert k0 == plan.csc_split[node] and ln == plan.cscptr[node + 1] - k0
+            genes = plan.csc_row[k0:k0 + ln]
+            for e in range(nu):
+                ke = plan.csc_split[node + e]
+                assert plan.cscptr[node + e + 1] - ke == ln and np.array_equal(plan.csc_row[ke:ke + ln], genes)
+                assert np.array_equal(plan.csc_k[ke:ke + ln], kb + e * ln + np.arange(ln))
     # levels tile the panel in reverse order and then the genes
     assert plan.level_begin[0] == C - plan.L and plan.level_end[0] == C
     for d in range(1, plan.K):
