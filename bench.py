@@ -442,19 +442,36 @@ def train_bench(model, dev, world, rank, B, steps, warmup, rows, profile=True, s
             phase_ms[name] = sum(buf[i] for i in range(cnt.value)) / nprobe
             phase_launches[name] = cnt.value / nprobe
         dom = max(phase_ms, key=phase_ms.get)
-        _lib.check(L.ontovae_profile_begin(1 << _lib.PHASES.index(dom), 16 * steps), "profile_begin")
+        # dW0 on one GPU: differential timing (include/ontovae_hip.h, ONTOVAE_PHASE_PAIR_A) -- alternate steps bracket the
+        # launch in front of dW0 alone and that launch plus dW0, with no event between the two kernels; the difference of the
+        # means is dW0 as it runs in an un-instrumented step.  Other kernels: one bracket per launch.
+        pair = dom == "dw0" and w == 1 and steps >= 8
+        mask = (1 << _lib.PHASE_PAIR_A) if pair else (1 << _lib.PHASES.index(dom))
+        _lib.check(L.ontovae_profile_begin(mask, 16 * steps), "profile_begin")
     dt = _timed(step, steps, w, dev)
+    pair_info = None
     if profile:
         kbuf = (C.c_float * (16 * steps))()
-        _lib.check(L.ontovae_profile_read(_lib.PHASES.index(dom), kbuf, 16 * steps, C.byref(cnt)), "profile_read")
-        launches = cnt.value
-        dom_ms_step = sum(kbuf[i] for i in range(launches)) / steps
+        if pair:
+            means = []
+            for ph in (_lib.PHASE_PAIR_A, _lib.PHASE_PAIR_AB):
+                _lib.check(L.ontovae_profile_read(ph, kbuf, 16 * steps, C.byref(cnt)), "profile_read")
+                v = np.array([kbuf[i] for i in range(cnt.value)], np.float64)
+                means.append((float(v.mean()), float(v.std() / np.sqrt(max(len(v), 1))), len(v)))
+            launches = steps
+            dom_ms_step = means[1][0] - means[0][0]
+            pair_info = {"front_launch_ms": means[0][0], "front_launch_plus_dw0_ms": means[1][0],
+                         "stderr_ms": float(np.hypot(means[0][1], means[1][1])), "brackets": [means[0][2], means[1][2]]}
+        else:
+            _lib.check(L.ontovae_profile_read(_lib.PHASES.index(dom), kbuf, 16 * steps, C.byref(cnt)), "profile_read")
+            launches = cnt.value
+            dom_ms_step = sum(kbuf[i] for i in range(launches)) / steps
         L.ontovae_profile_end()
     final = loss[:min(it[0], loss.shape[0])].cpu().numpy()
     assert np.isfinite(final).all(), "non-finite loss in the benchmark run"
     del X
     res = (dt, phase_ms, dom, dom_ms_step, launches / max(steps, 1), float(final[-1, 2]))
-    return res + (phase_launches,) if want_launches else res
+    return res + (phase_launches, pair_info) if want_launches else res
 
 
 def main():
@@ -552,7 +569,7 @@ def main():
         e = model._engine
         dist.barrier()
 
-    dt, phase_ms, dom, dom_ms_step, lps, final_loss, phase_launches = train_bench(model, dev, world, rank, B, a.steps, a.warmup, train_rows,
+    dt, phase_ms, dom, dom_ms_step, lps, final_loss, phase_launches, pair_info = train_bench(model, dev, world, rank, B, a.steps, a.warmup, train_rows,
                                                                                   want_launches=True)
     if a.breakdown and rank == 0:
         print("per-phase ms/step (event-bracketed, includes launch gaps):", {k: round(v, 4) for k, v in phase_ms.items()},
@@ -578,20 +595,32 @@ def main():
         kernels = [r for r in (roofline_entry(n, ms, d, rows_of(n), nnz_t, traffic, a.dtype, ov_est * launches_of(n))
                                for n, ms in phase_ms.items()) if r]
         roof = None
-        domr = roofline_entry(dom, dom_ms_step, d, rows_of(dom), nnz_t, traffic, a.dtype, ov_est * lps)
+        if pair_info is not None:
+            # differential timing: nothing to subtract; the raw single-launch bracket of the probe steps beside it
+            domr = roofline_entry(dom, dom_ms_step, d, rows_of(dom), nnz_t, traffic, a.dtype, 0.0)
+            ev = phase_ms[dom]
+            domr["us_events"], domr["frac_events"] = round(ev * 1e3, 2), round(domr["frac"] * dom_ms_step / ev, 4)
+            timer = ("HIP events on the launch stream inside the timed region, differential: even steps bracket the launch in "
+                     "front of dW0 (dWh + BatchNorm backward) alone, odd steps that launch and dW0 in one bracket with no event "
+                     "between the kernels; kernel_ms_per_step = mean(odd) - mean(even) and frac follow from it (dW0 as it runs in "
+                     "an un-instrumented step, its launch gap included); *_events = one bracket around dW0 alone in the probe "
+                     "steps, which reads 1-3 us more (the events hold the launch back)")
+        else:
+            domr = roofline_entry(dom, dom_ms_step, d, rows_of(dom), nnz_t, traffic, a.dtype, ov_est * lps)
+            timer = ("HIP events on the launch stream around every launch of the kernel inside the timed region; "
+                     "kernel_ms_per_step and frac are net of the bracket cost per launch, estimated live as (sum of all "
+                     "phases' brackets in the probe steps - wall time of an un-bracketed step) / launches per step; "
+                     "*_events are the raw brackets; null / empty-kernel brackets (ontovae_profile_overhead) are upper bounds")
         if domr is not None:
             unit = "TFLOP/s" if domr["bound"] == "mfma" else "GB/s"
             ach = domr["TFLOPs"] if domr["bound"] == "mfma" else domr["GBps"]
             roof = {"bound": domr["bound"], "achieved": ach, "peak": domr["peak"] / (1e3 if domr["bound"] == "mfma" else 1.0),
                     "unit": unit, "frac": domr["frac"], "frac_events": domr["frac_events"], "traffic": domr["traffic"],
                     "traffic_source": tmeta, "kernel": dom,
-                    "kernel_ms_per_step": domr["us"] * 1e-3, "kernel_ms_per_step_events": dom_ms_step,
+                    "kernel_ms_per_step": domr["us"] * 1e-3, "kernel_ms_per_step_events": domr["us_events"] * 1e-3,
+                    "differential": pair_info,
                     "event_bracket_overhead_ms": {"per_launch_estimate": ov_est, "null_bracket": ov_null, "empty_kernel_bracket": ov_empty},
-                    "launches_per_step": lps,
-                    "timer": "HIP events on the launch stream around every launch of the kernel inside the timed region; "
-                             "kernel_ms_per_step and frac are net of the bracket cost per launch, estimated live as (sum of all "
-                             "phases' brackets in the probe steps - wall time of an un-bracketed step) / launches per step; "
-                             "*_events are the raw brackets; null / empty-kernel brackets (ontovae_profile_overhead) are upper bounds",
+                    "launches_per_step": lps, "timer": timer,
                     "algorithmic_bytes": domr["algorithmic_bytes"], "algorithmic_flops": domr["algorithmic_flops"]}
         # whole-step roofline of BASELINE.md: max(F_s*B / mfma, (40 P + 4 G B) / hbm) / t_step
         P_real = d.L * d.G + 2 * d.L * d.L + int(d.nnz) + 6 * d.L + (d.C - d.L) + d.G
@@ -623,7 +652,7 @@ def main():
             out["screen"] = {k: scr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline")}
             m2, _ = build_model(dev)
             n1 = 30
-            dt1, ph1, _, _, _, _, pl1 = train_bench(m2, dev, 1, 0, GLOBAL_BATCH, n1, 6, train_rows, want_launches=True)
+            dt1, ph1, _, _, _, _, pl1, _ = train_bench(m2, dev, 1, 0, GLOBAL_BATCH, n1, 6, train_rows, want_launches=True)
             out["global_batch_8192_single_gpu"] = {
                 "metric": "train samples/sec at configs[2]'s global batch on one GPU", "value": GLOBAL_BATCH * n1 / dt1,
                 "unit": "samples/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1,

@@ -541,7 +541,12 @@ enum {
     ONTOVAE_PHASE_DW0 = 13,          /* dW0 = dh x (MFMA) + fused AdamW             */
     ONTOVAE_PHASE_DEC_BWD_GENE = 14, /* decoder backward data, gene layer           */
     ONTOVAE_PHASE_SELL_REFRESH = 15, /* packed term-level weight copies <- params   */
-    ONTOVAE_PHASE_COUNT = 16
+    /* Differential timing of dW0 (ontovae_train_step, single stream): with PAIR_A enabled, even-numbered steps bracket the launch
+     * in front of dW0 alone (slot PAIR_A), odd-numbered ones that launch and dW0 in ONE bracket with no event between them (slot
+     * PAIR_AB, filled whenever PAIR_A is enabled); mean(PAIR_AB) - mean(PAIR_A) = dW0 as it runs in an un-instrumented step. */
+    ONTOVAE_PHASE_PAIR_A = 16,
+    ONTOVAE_PHASE_PAIR_AB = 17,
+    ONTOVAE_PHASE_COUNT = 18
 };
 int ontovae_profile_begin(uint32_t phase_mask, int32_t capacity);
 int ontovae_profile_read(int32_t phase, float* ms, int32_t cap, int32_t* n_out);

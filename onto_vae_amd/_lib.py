@@ -188,6 +188,7 @@ FLAG_CB_GENE_FWD = 128       # training forward of the gene layer on 32-column b
 
 PHASES = ["enc_gemm", "bn_fwd", "heads", "reparam", "dec_fwd_terms", "dec_fwd_gene", "dec_bwd", "loss", "dec_wgrad",
           "latent_bwd", "da_gemm", "dwh", "bn_bwd", "dw0", "dec_bwd_gene", "sell_refresh"]
+PHASE_PAIR_A, PHASE_PAIR_AB = 16, 17     # differential timing of dW0 (include/ontovae_hip.h)
 
 
 def check(rc, what=""):

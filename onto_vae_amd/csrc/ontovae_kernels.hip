@@ -40,6 +40,34 @@ struct OvProfState {
 };
 static OvProfState g_prof;
 
+// Differential timing of the step's last kernel (dW0), free of what a bracket adds to the launch inside it: with phase
+// ONTOVAE_PHASE_PAIR_A enabled, even-numbered training steps bracket the launch before dW0 alone (dWh + BatchNorm backward) and
+// odd-numbered ones that launch AND dW0 in ONE bracket, with no event between the two kernels, as in an un-instrumented step
+// (slots PAIR_A / PAIR_AB).  mean(AB) - mean(A) is dW0's time in the pipeline, launch gap included.
+static int g_prof_pair_step = 0;
+static bool g_prof_pair_open = false;
+static inline bool ov_prof_pair_on() { return (g_prof.mask >> ONTOVAE_PHASE_PAIR_A) & 1u; }
+static void ov_prof_pair_begin(hipStream_t st) {
+    if (!ov_prof_pair_on()) return;
+    const int ph = (g_prof_pair_step & 1) ? ONTOVAE_PHASE_PAIR_AB : ONTOVAE_PHASE_PAIR_A;
+    g_prof_pair_open = g_prof.ev[ph] && g_prof.n[ph] < g_prof.cap;
+    if (g_prof_pair_open) (void)hipEventRecord(g_prof.ev[ph][2 * g_prof.n[ph]], st);
+}
+static void ov_prof_pair_close(hipStream_t st, int ph) {
+    (void)hipEventRecord(g_prof.ev[ph][2 * g_prof.n[ph] + 1], st);
+    g_prof.n[ph]++;
+    g_prof_pair_open = false;
+}
+static void ov_prof_pair_mid(hipStream_t st) {           // after the launch in front of dW0
+    if (g_prof_pair_open && !(g_prof_pair_step & 1)) ov_prof_pair_close(st, ONTOVAE_PHASE_PAIR_A);
+}
+static void ov_prof_pair_end(hipStream_t st) {           // after dW0
+    if (!ov_prof_pair_on()) return;
+    if (g_prof_pair_open && (g_prof_pair_step & 1)) ov_prof_pair_close(st, ONTOVAE_PHASE_PAIR_AB);
+    g_prof_pair_open = false;
+    g_prof_pair_step++;
+}
+
 struct OvProfScope {
     int phase; hipStream_t st; bool on;
     OvProfScope(int ph, hipStream_t s) : phase(ph), st(s), on(false) {
@@ -80,6 +108,14 @@ extern "C" int ontovae_profile_begin(uint32_t phase_mask, int32_t capacity) {
         if (!((phase_mask >> ph) & 1u)) continue;
         g_prof.ev[ph] = new hipEvent_t[2 * capacity];
         for (int i = 0; i < 2 * capacity; ++i) OV_HIP_CHECK(hipEventCreateWithFlags(&g_prof.ev[ph][i], hipEventDisableSystemFence));      // no system-scope release (L2 write-back) charged to the bracketed kernel
+    }
+    if ((phase_mask >> ONTOVAE_PHASE_PAIR_A) & 1u) {       // the pair mode needs both slots
+        if (!g_prof.ev[ONTOVAE_PHASE_PAIR_AB]) {
+            g_prof.ev[ONTOVAE_PHASE_PAIR_AB] = new hipEvent_t[2 * capacity];
+            for (int i = 0; i < 2 * capacity; ++i) OV_HIP_CHECK(hipEventCreateWithFlags(&g_prof.ev[ONTOVAE_PHASE_PAIR_AB][i], hipEventDisableSystemFence));
+        }
+        g_prof_pair_step = 0;
+        g_prof_pair_open = false;
     }
     g_prof.mask = phase_mask;
     return ONTOVAE_OK;
@@ -3735,12 +3771,16 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                          apply, adam, c->drop, c->seed, rng_off, da_S, (int64_t)d.L * s.ldb, nullptr, 0};
     const int bn_blocks = d.L;
     if (!s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS)) {
-        OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
-        const int gx = (gw.N + 31) / 32, gy = (gw.M + 31) / 32;
-        const size_t lds = (size_t)4 * 16 * 64 * sizeof(float);
-        if (apply) hipLaunchKernelGGL((ov_dwh_bn_kernel<OV_EPI_ADAMW>), dim3(gx * gy + bn_blocks), dim3(256), lds, s.st, gw, gx, gy, bn);
-        else hipLaunchKernelGGL((ov_dwh_bn_kernel<OV_EPI_STORE>), dim3(gx * gy + bn_blocks), dim3(256), lds, s.st, gw, gx, gy, bn);
-        OV_LAUNCH_CHECK();
+        ov_prof_pair_begin(s.st);
+        {
+            OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
+            const int gx = (gw.N + 31) / 32, gy = (gw.M + 31) / 32;
+            const size_t lds = (size_t)4 * 16 * 64 * sizeof(float);
+            if (apply) hipLaunchKernelGGL((ov_dwh_bn_kernel<OV_EPI_ADAMW>), dim3(gx * gy + bn_blocks), dim3(256), lds, s.st, gw, gx, gy, bn);
+            else hipLaunchKernelGGL((ov_dwh_bn_kernel<OV_EPI_STORE>), dim3(gx * gy + bn_blocks), dim3(256), lds, s.st, gw, gx, gy, bn);
+            OV_LAUNCH_CHECK();
+        }
+        ov_prof_pair_mid(s.st);
         return ONTOVAE_OK;
     }
     const bool dwh_main = OV_DBG((c->flags & 64u) != 0);
@@ -3841,6 +3881,7 @@ extern "C" int ontovae_train_step(const ontovae_ctx_t* ctx, const float* x, cons
     if ((rc = ov_bn_fwd(s, S, 1, B, nullptr, rng_offset))) return rc;
     if ((rc = ov_train_tail_a(s, eps, rng_offset, kl_coeff, opt, apply_update, loss_out, 1, nullptr, B, refreshed))) return rc;
     if ((rc = ov_dw0(s, opt, apply_update))) return rc;
+    ov_prof_pair_end(s.st);
     return ov_side_join(s);
 }
 

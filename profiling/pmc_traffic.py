@@ -4,10 +4,10 @@ Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counte
 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRITE_SIZE is taken as is.
     python profiling/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
 """
-import csv, collections, json, sys
+import csv, collections, datetime, json, subprocess, sys
 
 PHASE_OF = {"ov_dw0_kernel": "dw0", "ov_gemm_lds_kernel": "enc_gemm", "ov_gene_cb_kernel": "dec_fwd_gene",
-            "ov_bwd_gene_cb_kernel": "dec_bwd_gene", "ov_chain_bwd_finish_kernel": "dec_bwd",
+            "ov_bwd_gene_cb_kernel": "dec_bwd_gene", "ov_bwd_gene_term": "dec_bwd_gene", "ov_chain_bwd_finish_kernel": "dec_bwd",
             "ov_dec_chain_kernel": "dec_fwd_terms", "ov_chain_fwd_refresh_kernel": "dec_fwd_terms", "ov_latent_bwd_kernel": "latent_bwd", "ov_da_gemm_kernel": "da_gemm",
             "ov_dwh_bn_kernel": "dwh", "ov_bn_fwd_kernel": "bn_fwd", "ov_reparam_kernel": "reparam", "ov_gemm_kernel<1, 1, 4, 4": "heads"}
 
@@ -24,7 +24,15 @@ def per_kernel(path, counter):
 def main():
     f = per_kernel(sys.argv[1], "FETCH_SIZE")
     w = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"_note": "bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950 correction: FETCH_SIZE doubled); "
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "onto_vae_amd/csrc"], capture_output=True, text=True).stdout.strip())
+    except OSError:
+        commit, dirty = "unknown", False
+    out = {"_meta": {"commit": commit + ("+uncommitted kernel changes" if dirty else ""), "date": datetime.date.today().isoformat(),
+                     "sources": [sys.argv[1], sys.argv[2]],
+                     "what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiling/one_step.py 6 128 train, NOT of the bench process"},
+           "_note": "bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950 correction: FETCH_SIZE doubled); "
                     "mean of the second half of the launches of a 6-step run; Infinity-Cache hits are counted",
            "kernels": {}}
     for k in sorted(set(f) | set(w)):

@@ -724,6 +724,11 @@ def test_bench_line_is_self_consistent(args):
     roof = d["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and 0.0 < roof["frac"] <= 1.0
     assert roof["kernel_ms_per_step"] <= roof["kernel_ms_per_step_events"] <= 1.1 * roof["kernel_ms_per_step"]
+    if roof["kernel"] == "dw0":
+        # differential timing: alternate steps bracket (dWh + BN backward) and (dWh + BN backward, dW0); both halves were taken
+        p = roof["differential"]
+        assert p["brackets"] == [15, 15] and p["front_launch_plus_dw0_ms"] > p["front_launch_ms"] > 0.0
+        assert abs((p["front_launch_plus_dw0_ms"] - p["front_launch_ms"]) - roof["kernel_ms_per_step"]) < 1e-4
     assert d["dtype"] == ("bf16" if "bf16" in args else "f32") and 0.0 < d["step_roofline_frac"] <= 1.0
     if "bf16" in args:
         assert any(k["kernel"] == "enc_gemm" and (k["bound"] == "hbm" or k["peak"] == 2.5e6) for k in d["roofline_kernels"])
