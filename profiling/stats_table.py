@@ -4,6 +4,12 @@ import csv
 import re
 import sys
 
+def label(path):
+    parts = path.split("/")
+    stem = parts[-1].replace("_kernel_stats.csv", "").replace(".csv", "")
+    return parts[-2] if stem in ("t", "t_kernel_stats") and len(parts) > 1 else stem
+
+
 cols, names = [], []
 for arg in sys.argv[1:]:
     steps, path = arg.split(":", 1)
@@ -19,7 +25,7 @@ for arg in sys.argv[1:]:
             names.append(n)
     cols.append(d)
 names.sort(key=lambda n: -max(c.get(n, (0, 0))[0] for c in cols))
-print("%-62s" % "kernel (us per step, launches per step)" + "".join("%18s" % a.split(":", 1)[1].split("/")[-2] for a in sys.argv[1:]))
+print("%-62s" % "kernel (us per step, launches per step)" + "".join("%18s" % label(a.split(":", 1)[1]) for a in sys.argv[1:]))
 for n in names:
     print("%-62s" % n[:62] + "".join(("%12.1f x%-4.3g" % c[n]) if n in c else "%18s" % "-" for c in cols))
 print("%-62s" % "sum" + "".join("%12.1f      " % sum(v[0] for v in c.values()) for c in cols))
