@@ -593,6 +593,11 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
 // offset beyond num_records, which the hardware reads as 0 and does not store, so partial tiles need no
 // branches.  (Vector memory path; offsets are 32-bit, the host checks M * ldc * 4 < 2^31.)
 typedef int32_t ov_i32x4 __attribute__((ext_vector_type(4)));
+// The dW0 kernels keep the batch's x rows in LDS as 64-bit ELEMENT OFFSETS (row * ldb), not row indices: a gathered x load then
+// costs one 64-bit shift-add; with indices every load paid a sign extension, two 32-bit multiplies, a 64-bit multiply-add and
+// two adds (quarter-rate integer ops, ~60 cycles; 32 loads per 64-row chunk and wave = a fifth of the chunk's MFMA time, and
+// both waves of a SIMD did it at the same moment, before either had an MFMA to issue).
+typedef int64_t ov_i64x2 __attribute__((ext_vector_type(2)));
 __device__ float ov_buf_load(ov_i32x4 rsrc, int32_t voffset, int32_t soffset, int32_t aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void ov_buf_store(float v, ov_i32x4 rsrc, int32_t voffset, int32_t soffset, int32_t aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 __device__ __forceinline__ ov_i32x4 ov_buf_rsrc(const void* base, uint32_t bytes) {
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
     constexpr int LT = 4, RA = 32 * LT, KMAX = 128, LDA = KMAX + 4;
     extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
     float* As = ov_gemm_lds;                                             // [RA][LDA]
-    int32_t* rows = reinterpret_cast<int32_t*>(ov_gemm_lds + RA * LDA);  // [KMAX]; beyond K: the last row (dh is 0 there)
+    int64_t* rows = reinterpret_cast<int64_t*>(ov_gemm_lds + RA * LDA);  // [KMAX] element offsets of the x rows; beyond K: the last row (dh is 0 there)
     const int tid = threadIdx.x;
     const int lane = ov_lane();
     const int wave = ov_wave_id();
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
     }
     for (int t = tid; t < KMAX; t += 64 * NW) {
         const int tt = min(t, p.K - 1);
-        rows[t] = p.bgather ? p.bgather[tt] : tt;
+        rows[t] = (int64_t)(p.bgather ? p.bgather[tt] : tt) * p.ldb;
     }
     __syncthreads();
     OV_PROBE(1);
@@ -689,11 +694,12 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
         const float* xcol = p.B + min(n0 + i, p.N - 1);
 #pragma unroll
         for (int s = 0; s < KMAX / 8; ++s) {
-            const int4 rr = *reinterpret_cast<const int4*>(rows + 8 * s + 4 * h);
-            xb[4 * s + 0] = xcol[(int64_t)rr.x * p.ldb];
-            xb[4 * s + 1] = xcol[(int64_t)rr.y * p.ldb];
-            xb[4 * s + 2] = xcol[(int64_t)rr.z * p.ldb];
-            xb[4 * s + 3] = xcol[(int64_t)rr.w * p.ldb];
+            const ov_i64x2 r01 = *reinterpret_cast<const ov_i64x2*>(rows + 8 * s + 4 * h);
+            const ov_i64x2 r23 = *reinterpret_cast<const ov_i64x2*>(rows + 8 * s + 4 * h + 2);
+            xb[4 * s + 0] = xcol[r01.x];
+            xb[4 * s + 1] = xcol[r01.y];
+            xb[4 * s + 2] = xcol[r23.x];
+            xb[4 * s + 3] = xcol[r23.y];
         }
     }
     OV_PROBE(2);
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_multi_kernel(const OvGemm p, i
     constexpr int LT = 4, RA = 32 * LT, KC = 128, LDA = KC + 4;
     extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
     float* As = ov_gemm_lds;                                             // [RA][LDA]
-    int32_t* rows = reinterpret_cast<int32_t*>(ov_gemm_lds + RA * LDA);  // [KC]
+    int64_t* rows = reinterpret_cast<int64_t*>(ov_gemm_lds + RA * LDA);  // [KC] element offsets of the chunk's x rows
     const int tid = threadIdx.x;
     const int lane = ov_lane();
     const int wave = ov_wave_id();
@@ -837,18 +843,19 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_multi_kernel(const OvGemm p, i
         for (int t = tid; t < KC; t += 64 * NW) {
             int tt = min(kc + t, p.K - 1);
             if (p.colmap) tt = p.colmap[tt];
-            rows[t] = p.bgather ? p.bgather[tt] : tt;
+            rows[t] = (int64_t)(p.bgather ? p.bgather[tt] : tt) * p.ldb;
         }
         __syncthreads();
         float xb[KC / 2];
         if (wave_on) {
 #pragma unroll
             for (int s = 0; s < KC / 8; ++s) {
-                const int4 rr = *reinterpret_cast<const int4*>(rows + 8 * s + 4 * h);
-                xb[4 * s + 0] = xcol[(int64_t)rr.x * p.ldb];
-                xb[4 * s + 1] = xcol[(int64_t)rr.y * p.ldb];
-                xb[4 * s + 2] = xcol[(int64_t)rr.z * p.ldb];
-                xb[4 * s + 3] = xcol[(int64_t)rr.w * p.ldb];
+                const ov_i64x2 r01 = *reinterpret_cast<const ov_i64x2*>(rows + 8 * s + 4 * h);
+                const ov_i64x2 r23 = *reinterpret_cast<const ov_i64x2*>(rows + 8 * s + 4 * h + 2);
+                xb[4 * s + 0] = xcol[r01.x];
+                xb[4 * s + 1] = xcol[r01.y];
+                xb[4 * s + 2] = xcol[r23.x];
+                xb[4 * s + 3] = xcol[r23.y];
             }
         }
 #pragma unroll
@@ -922,14 +929,14 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_multi_kernel(const OvGemm p, i
 // 197 us at 1024 rows, 1.21 against 1.23 ms at 8192 (both MFMA-paced: 0.62 of the fp32 peak on the algorithmic flops, 0.72
 // on the issued ones, with 237 workgroups on 256 CUs and 384 rows of tiles for 360 rows); the multi kernel stays for batches
 // whose row indices do not fit LDS.
-// Dynamic LDS: 2 * 128 * 68 floats + round_up(K, 64) ints.
+// Dynamic LDS: 2 * 128 * 68 floats + round_up(K, 64) 64-bit offsets.
 template <int NW, int EPI>
 __global__ __launch_bounds__(64 * NW) void ov_dw0_pipe_kernel(const OvGemm p, int njobs) {
     constexpr int LT = 4, RA = 32 * LT, KC = 64, LDA = KC + 4;
     extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
     float* As0 = ov_gemm_lds;                                            // [RA][LDA] x 2
     float* As1 = As0 + RA * LDA;
-    int32_t* rows = reinterpret_cast<int32_t*>(As1 + RA * LDA);          // [round_up(K, KC)]; beyond K: the last row (dh is 0 there)
+    int64_t* rows = reinterpret_cast<int64_t*>(As1 + RA * LDA);          // [round_up(K, KC)] element offsets of the x rows; beyond K: the last row (dh is 0 there)
     const int tid = threadIdx.x;
     const int lane = ov_lane();
     const int wave = ov_wave_id();
@@ -961,7 +968,7 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_pipe_kernel(const OvGemm p, in
     for (int t = tid; t < kpad; t += 64 * NW) {
         int tt = min(t, p.K - 1);
         if (p.colmap) tt = p.colmap[tt];
-        rows[t] = p.bgather ? p.bgather[tt] : tt;
+        rows[t] = (int64_t)(p.bgather ? p.bgather[tt] : tt) * p.ldb;
     }
 
     f32x16 acc[LT];
@@ -971,83 +978,123 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_pipe_kernel(const OvGemm p, in
         for (int r = 0; r < 16; ++r) acc[lt][r] = 0.f;
 
     constexpr int SU = RA * (KC / 4) / (64 * NW);
+    // No lane-dependent control flow around the loads of the K loop: every lane issues the same loads at clamped addresses and
+    // the out-of-range elements are zeroed by selects (store_a), so that the compiler's wait-count bookkeeping stays exact.  With
+    // branches around them it fell back to "wait for everything" in front of every slab store and made the MFMAs of a chunk wait
+    // for the NEXT chunk's x loads one by one (30 % of the kernel at s_waitcnt: profiles/r03/gemm_counters.txt).
+    // A row's 16-B pieces never cross its end: lda % 4 == 0 and lda >= K (host check), rank blocks are multiples of 4 columns.
+    const int klast = (p.K - 1) & ~3;
     auto load_a = [&](int kc, f32x4 (&sv)[SU]) {
 #pragma unroll
         for (int q = 0; q < SU; ++q) {
             const int u = tid + q * 64 * NW;
-            const int r = u / (KC / 4), k = kc + 4 * (u % (KC / 4));
-            const int m = m0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < p.M && k < p.K) {
-                const int rb = k / blm, j = k - rb * blm;
-                const float* src = p.A + (int64_t)rb * p.a_rstride + (int64_t)m * p.lda + j;
-                if (k + 3 < p.K && j + 3 < blm) v = *reinterpret_cast<const f32x4*>(src);
-                else {                          // the last columns of the batch (never across a rank block: a_blm % 4 == 0)
-                    v.x = src[0];
-                    v.y = k + 1 < p.K ? src[1] : 0.f;
-                    v.z = k + 2 < p.K ? src[2] : 0.f;
-                }
-            }
-            sv[q] = v;
+            const int r = u / (KC / 4), k = min(kc + 4 * (u % (KC / 4)), klast);
+            const int m = min(m0 + r, p.M - 1);
+            int rb = 0, j = k;
+            if (p.a_blm > 0) { rb = k / blm; j = k - rb * blm; }          // uniform
+            sv[q] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)rb * p.a_rstride + (int64_t)m * p.lda + j);
         }
     };
-    auto store_a = [&](float* As, const f32x4 (&sv)[SU]) {
+    auto store_a = [&](float* As, int kc, const f32x4 (&sv)[SU]) {
 #pragma unroll
         for (int q = 0; q < SU; ++q) {
             const int u = tid + q * 64 * NW;
-            *reinterpret_cast<f32x4*>(As + (u / (KC / 4)) * LDA + 4 * (u % (KC / 4))) = sv[q];
+            const int r = u / (KC / 4), k = kc + 4 * (u % (KC / 4));
+            const bool ok = m0 + r < p.M;
+            f32x4 v;
+            v.x = ok && k < p.K ? sv[q].x : 0.f;
+            v.y = ok && k + 1 < p.K ? sv[q].y : 0.f;
+            v.z = ok && k + 2 < p.K ? sv[q].z : 0.f;
+            v.w = ok && k + 3 < p.K ? sv[q].w : 0.f;
+            *reinterpret_cast<f32x4*>(As + r * LDA + 4 * (u % (KC / 4))) = v;
         }
     };
     auto load_x = [&](int kc, float (&xb)[KC / 2]) {
 #pragma unroll
         for (int s = 0; s < KC / 8; ++s) {
-            const int4 rr = *reinterpret_cast<const int4*>(rows + kc + 8 * s + 4 * h);
-            xb[4 * s + 0] = xcol[(int64_t)rr.x * p.ldb];
-            xb[4 * s + 1] = xcol[(int64_t)rr.y * p.ldb];
-            xb[4 * s + 2] = xcol[(int64_t)rr.z * p.ldb];
-            xb[4 * s + 3] = xcol[(int64_t)rr.w * p.ldb];
+            const ov_i64x2 r01 = *reinterpret_cast<const ov_i64x2*>(rows + kc + 8 * s + 4 * h);
+            const ov_i64x2 r23 = *reinterpret_cast<const ov_i64x2*>(rows + kc + 8 * s + 4 * h + 2);
+            xb[4 * s + 0] = xcol[r01.x];
+            xb[4 * s + 1] = xcol[r01.y];
+            xb[4 * s + 2] = xcol[r23.x];
+            xb[4 * s + 3] = xcol[r23.y];
         }
     };
-    auto mfmas = [&](const float* As, const float (&xb)[KC / 2]) {
+    // One chunk: its 128 MFMAs with everything the NEXT chunk needs issued in between them, in ONE basic block.  Both waves of a
+    // SIMD leave the chunk barrier together; while the loads and their address arithmetic stood in front of the MFMAs, neither
+    // wave had an MFMA to issue for that long and the matrix pipe idled a fifth of every chunk (register-only and LDS-fed
+    // loops of the same MFMAs run at 155 TFLOP/s, scratch/mfma_probe).  Eight groups (one per 8 k): the four tiles' fragments
+    // of group s + 1 and the x-row offsets of the next chunk's group s + 1 are requested from LDS, the next chunk's x loads of
+    // group s are issued, then the 16 MFMAs of group s run, the four accumulators taking turns (k ascending inside each, as in
+    // ov_dw0_multi_kernel: same bits).  All four tiles are computed even where a workgroup's last tiles lie beyond M (their
+    // dh rows are zeros in LDS and they are never stored): no branch inside the block.
+    auto chunk = [&](const float* As, const float (&xc)[KC / 2], float (&xn)[KC / 2], int kn, f32x4 (&sv)[SU]) {
+        const float* asrc[SU];
 #pragma unroll
-        for (int lt = 0; lt < LT; ++lt) {
-            if (m0 + 32 * lt < p.M) {            // uniform
-                const float* arow = As + (32 * lt + i) * LDA + 4 * h;
+        for (int q = 0; q < SU; ++q) {
+            const int u = tid + q * 64 * NW;
+            const int r = u / (KC / 4), k = min(kn + 4 * (u % (KC / 4)), klast);
+            const int m = min(m0 + r, p.M - 1);
+            int rb = 0, j = k;
+            if (p.a_blm > 0) { rb = k / blm; j = k - rb * blm; }          // uniform
+            asrc[q] = p.A + (int64_t)rb * p.a_rstride + (int64_t)m * p.lda + j;
+        }
+        const float* arow = As + i * LDA + 4 * h;
+        const int64_t* rown = rows + kn + 4 * h;
+        f32x4 fa[2][LT];
+        ov_i64x2 ro[2][2];
 #pragma unroll
-                for (int s = 0; s < KC / 8; ++s) {
-                    const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + 8 * s);
+        for (int lt = 0; lt < LT; ++lt) fa[0][lt] = *reinterpret_cast<const f32x4*>(arow + 32 * lt * LDA);
+        ro[0][0] = *reinterpret_cast<const ov_i64x2*>(rown);
+        ro[0][1] = *reinterpret_cast<const ov_i64x2*>(rown + 2);
+        // the slab loads first, ahead of the chunk's x loads (measured in scratch/mfma_probe: 18.7 k against 19.8 k cycles per
+        // chunk when they are spread over the first four groups)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], xb[4 * s + t], acc[lt], 0, 0, 0);
-                }
+        for (int q = 0; q < SU; ++q) sv[q] = *reinterpret_cast<const f32x4*>(asrc[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KC / 8; ++s) {
+            const int c = s & 1, n = c ^ 1;
+            if (s + 1 < KC / 8) {
+#pragma unroll
+                for (int lt = 0; lt < LT; ++lt) fa[n][lt] = *reinterpret_cast<const f32x4*>(arow + 32 * lt * LDA + 8 * (s + 1));
             }
+            xn[4 * s + 0] = xcol[ro[c][0].x];
+            xn[4 * s + 1] = xcol[ro[c][0].y];
+            xn[4 * s + 2] = xcol[ro[c][1].x];
+            xn[4 * s + 3] = xcol[ro[c][1].y];
+            if (s + 1 < KC / 8) {
+                ro[n][0] = *reinterpret_cast<const ov_i64x2*>(rown + 8 * (s + 1));
+                ro[n][1] = *reinterpret_cast<const ov_i64x2*>(rown + 8 * (s + 1) + 2);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int lt = 0; lt < LT; ++lt) acc[lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][lt][t], xc[4 * s + t], acc[lt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     f32x4 sv[SU];
     float xa[KC / 2], xb[KC / 2];
+    // The loads of the next chunk are issued on EVERY path (waves beyond N and the last chunk included: clamped addresses, results
+    // unused), never inside a branch: where a path without them joins one with them the compiler must place waits that are right
+    // for both, and "the slab loads are the youngest four" of the path without x loads made every slab store wait for the x
+    // prefetch as well (and the MFMAs of a chunk for the next chunk's loads).
+    const int kend = kpad - KC;
     load_a(0, sv);
-    __syncthreads();                                 // the row indices are in LDS
-    if (wave_on) load_x(0, xa);
-    store_a(As0, sv);
+    __syncthreads();                                 // the row offsets are in LDS
+    load_x(0, xa);
+    store_a(As0, 0, sv);
     __syncthreads();
 #pragma unroll 1
     for (int kc = 0; kc < p.K; kc += 2 * KC) {
-        const bool more1 = kc + KC < p.K;            // workgroup-uniform, like more2
-        if (more1) {
-            load_a(kc + KC, sv);
-            if (wave_on) load_x(kc + KC, xb);
-        }
-        if (wave_on) mfmas(As0, xa);
-        if (!more1) break;
-        store_a(As1, sv);
+        chunk(As0, xa, xb, min(kc + KC, kend), sv);
+        if (kc + KC >= p.K) break;                   // workgroup-uniform
+        store_a(As1, kc + KC, sv);
         __syncthreads();                             // slab kc + KC is in LDS, and everybody is done reading As0
-        const bool more2 = kc + 2 * KC < p.K;
-        if (more2) {
-            load_a(kc + 2 * KC, sv);
-            if (wave_on) load_x(kc + 2 * KC, xa);
-        }
-        if (wave_on) mfmas(As1, xb);
-        if (!more2) break;
-        store_a(As0, sv);
+        chunk(As1, xb, xa, min(kc + 2 * KC, kend), sv);
+        if (kc + 2 * KC >= p.K) break;
+        store_a(As0, kc + 2 * KC, sv);
         __syncthreads();
     }
     if (!wave_on) return;

@@ -2768,10 +2768,10 @@ static int ov_launch_dw0(const OvGemm& g, hipStream_t st) {
     const int njobs = (g.M + 127) / 128;
     const int gxn = (g.N + 32 * NW - 1) / (32 * NW);
     const int blocks = (gxn + 7) / 8 * 8 * njobs;
-    size_t lds = (size_t)128 * 132 * sizeof(float) + 128 * sizeof(int32_t);
+    size_t lds = (size_t)128 * 132 * sizeof(float) + 128 * sizeof(int64_t);
     auto kern = (g.K <= 128 && g.a_blm == 0) ? ov_dw0_kernel<NW, EPI> : ov_dw0_multi_kernel<NW, EPI>;
     // more than one chunk of the batch: the pipelined kernel, while the whole batch's row indices fit LDS beside its two slabs
-    const size_t lds_pipe = (size_t)2 * 128 * 68 * sizeof(float) + (size_t)((g.K + 63) / 64 * 64) * sizeof(int32_t);
+    const size_t lds_pipe = (size_t)2 * 128 * 68 * sizeof(float) + (size_t)((g.K + 63) / 64 * 64) * sizeof(int64_t);
     if (!(g.K <= 128 && g.a_blm == 0) && lds_pipe <= (size_t)160 * 1024 - 512) { kern = ov_dw0_pipe_kernel<NW, EPI>; lds = lds_pipe; }
     { int rc_ = ov_allow_lds(reinterpret_cast<const void*>(kern), lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, g, njobs);
