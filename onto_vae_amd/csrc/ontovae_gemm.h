@@ -459,49 +459,68 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
         } else {
             constexpr int Q = RB / 4;                         // float4 per k row
             const int k = unit / Q, q = unit % Q;
-            bsrc[u] = p.B + n0 + 4 * q;
+            bsrc[u] = p.B + (n0 + 4 * q < p.N ? n0 + 4 * q : 0);  // beyond N: a valid address, the piece is zeroed (bok); a piece that
+                                                                  // starts below N may end in the row's padding (ldb >= N rounded up to 4)
             bdst[u] = k * LDN + 4 * q;
             bk[u] = k;
             bok[u] = k < BK && n0 + 4 * q < p.N;
         }
     }
+    // Stage loads without lane-dependent control flow: every lane issues every load at an address clamped into its row, and the
+    // elements beyond the K range are zeroed by selects where the stage goes to LDS.  With the tail handled by branches (one
+    // 16-B load or up to three 4-B loads plus zero fills of the same registers) the compiler put a wait for ALL outstanding
+    // loads behind every load of a stage -- a later write to a register that an earlier path still had a load pending on --
+    // so the seven loads of a stage went out one memory latency after the other, in front of the stage's MFMAs.
+    // Rows are 16-B aligned and lda, ldb are multiples of 4 that cover the range (host check), so a piece stays inside its row;
+    // a clamped piece lies wholly beyond the K range.
     f32x4 ra[UA], rb[UB];
+    const int kclamp = (p.K - 1) & ~3;             // the last 16-B piece of a row that holds an element of the K range
     auto gload = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
-            const int k = k0 + 4 * ((tid + 256 * u) & 7);
-            if (k + 3 < kb1) ra[u] = *reinterpret_cast<const f32x4*>(asrc[u] + k0);
-            else {
-                ra[u].x = k < kb1 ? asrc[u][k0] : 0.f;
-                ra[u].y = k + 1 < kb1 ? asrc[u][k0 + 1] : 0.f;
-                ra[u].z = k + 2 < kb1 ? asrc[u][k0 + 2] : 0.f;
-                ra[u].w = 0.f;
+            const int k = min(k0 + 4 * ((tid + 256 * u) & 7), kclamp);
+            ra[u] = *reinterpret_cast<const f32x4*>(asrc[u] + (k - 4 * ((tid + 256 * u) & 7)));
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (B_KC) {
+                const int k = min(k0 + 4 * ((tid + 256 * u) & 7), kclamp);
+                rb[u] = *reinterpret_cast<const f32x4*>(bsrc[u] + (k - 4 * ((tid + 256 * u) & 7)));
+            } else {
+                const int k = min(k0 + bk[u], kb1 - 1);
+                rb[u] = *reinterpret_cast<const f32x4*>(bsrc[u] + (int64_t)rows[k - kb0] * p.ldb);
             }
+        }
+    };
+    // (a piece whose address was clamped starts at or beyond kb1 in unclamped terms: all four of its elements are zeroed)
+    auto lstore = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int k = k0 + 4 * ((tid + 256 * u) & 7);
+            f32x4 v;
+            v.x = k < kb1 ? ra[u].x : 0.f;
+            v.y = k + 1 < kb1 ? ra[u].y : 0.f;
+            v.z = k + 2 < kb1 ? ra[u].z : 0.f;
+            v.w = k + 3 < kb1 ? ra[u].w : 0.f;
+            *reinterpret_cast<f32x4*>(As + adst[u]) = v;
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             if (B_KC) {
                 const int k = k0 + 4 * ((tid + 256 * u) & 7);
-                if (k + 3 < kb1) rb[u] = *reinterpret_cast<const f32x4*>(bsrc[u] + k0);
-                else {
-                    rb[u].x = k < kb1 ? bsrc[u][k0] : 0.f;
-                    rb[u].y = k + 1 < kb1 ? bsrc[u][k0 + 1] : 0.f;
-                    rb[u].z = k + 2 < kb1 ? bsrc[u][k0 + 2] : 0.f;
-                    rb[u].w = 0.f;
-                }
-            } else {
-                const int k = k0 + bk[u];
-                if (bok[u] && k < kb1) rb[u] = *reinterpret_cast<const f32x4*>(bsrc[u] + (int64_t)rows[k - kb0] * p.ldb);
-                else rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 v;
+                v.x = k < kb1 ? rb[u].x : 0.f;
+                v.y = k + 1 < kb1 ? rb[u].y : 0.f;
+                v.z = k + 2 < kb1 ? rb[u].z : 0.f;
+                v.w = k + 3 < kb1 ? rb[u].w : 0.f;
+                *reinterpret_cast<f32x4*>(Bs + bdst[u]) = v;
+            } else if (bk[u] < BK) {                 // (compile-time per u except for the last unit)
+                const bool ok = bok[u] && k0 + bk[u] < kb1;
+                f32x4 v;
+                v.x = ok ? rb[u].x : 0.f; v.y = ok ? rb[u].y : 0.f; v.z = ok ? rb[u].z : 0.f; v.w = ok ? rb[u].w : 0.f;
+                *reinterpret_cast<f32x4*>(Bs + bdst[u]) = v;
             }
         }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int u = 0; u < UA; ++u) *reinterpret_cast<f32x4*>(As + adst[u]) = ra[u];
-#pragma unroll
-        for (int u = 0; u < UB; ++u)
-            if (B_KC || bk[u] < BK) *reinterpret_cast<f32x4*>(Bs + bdst[u]) = rb[u];
     };
 
     f32x16 acc[MT];
@@ -510,12 +529,13 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    if (kb0 < kb1) gload(kb0);
+    gload(kb0);
     for (int k0 = kb0; k0 < kb1; k0 += BK) {
         __syncthreads();                  // everybody is done reading the previous stage
-        lstore();
+        lstore(k0);
         __syncthreads();
-        if (k0 + BK < kb1) gload(k0 + BK);      // next stage in flight under this stage's MFMAs
+        gload(k0 + BK);                         // next stage in flight under this stage's MFMAs (beyond the range: clamped, unused)
+        __builtin_amdgcn_sched_barrier(0);      // (in one block with the MFMAs now: keep the scheduler from sinking the loads below them)
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
             f32x4 fa[MT], fb;
@@ -665,23 +685,16 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
     // Prologue, ordered by what the first MFMA needs (memory returns in issue order): the dh slab and the
     // x fragment first, then the first tile's parameters; the slab goes to LDS once it has landed.
     constexpr int SU = RA * (KMAX / 4) / (64 * NW);
+    // slab loads without lane-dependent branches (clamped addresses, out-of-range elements zeroed by selects where the slab goes
+    // to LDS): with branches around them the compiler made the slab's LDS stores wait for the 64 x loads issued after them as
+    // well, and the first tile's parameter request went out only once all of x had landed.  lda % 4 == 0 and lda >= K (host check).
     f32x4 sv[SU];
+    const int klast = (p.K - 1) & ~3;
 #pragma unroll
     for (int q = 0; q < SU; ++q) {
         const int u = tid + q * 64 * NW;
-        const int r = u / (KMAX / 4), k = 4 * (u % (KMAX / 4));
-        const int m = m0 + r;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < p.M) {
-            const float* src = p.A + (int64_t)m * p.lda + k;
-            if (k + 3 < p.K) v = *reinterpret_cast<const f32x4*>(src);
-            else {
-                v.x = k < p.K ? src[0] : 0.f;
-                v.y = k + 1 < p.K ? src[1] : 0.f;
-                v.z = k + 2 < p.K ? src[2] : 0.f;
-            }
-        }
-        sv[q] = v;
+        const int r = u / (KMAX / 4), k = min(4 * (u % (KMAX / 4)), klast);
+        sv[q] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)min(m0 + r, p.M - 1) * p.lda + k);
     }
     for (int t = tid; t < KMAX; t += 64 * NW) {
         const int tt = min(t, p.K - 1);
@@ -690,7 +703,7 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
     __syncthreads();
     OV_PROBE(1);
     float xb[KMAX / 2];
-    if (wave_on) {
+    {                                            // on every path (waves beyond N: clamped column, result unused)
         const float* xcol = p.B + min(n0 + i, p.N - 1);
 #pragma unroll
         for (int s = 0; s < KMAX / 8; ++s) {
@@ -706,7 +719,14 @@ __global__ __launch_bounds__(64 * NW) void ov_dw0_kernel(const OvGemm p, int njo
 #pragma unroll
     for (int q = 0; q < SU; ++q) {
         const int u = tid + q * 64 * NW;
-        *reinterpret_cast<f32x4*>(As + (u / (KMAX / 4)) * LDA + 4 * (u % (KMAX / 4))) = sv[q];
+        const int r = u / (KMAX / 4), k = 4 * (u % (KMAX / 4));
+        const bool ok = m0 + r < p.M;
+        f32x4 v;
+        v.x = ok && k < p.K ? sv[q].x : 0.f;
+        v.y = ok && k + 1 < p.K ? sv[q].y : 0.f;
+        v.z = ok && k + 2 < p.K ? sv[q].z : 0.f;
+        v.w = ok && k + 3 < p.K ? sv[q].w : 0.f;
+        *reinterpret_cast<f32x4*>(As + r * LDA + k) = v;
     }
     __syncthreads();
     if (!wave_on) return;                       // wave-uniform; no barrier below

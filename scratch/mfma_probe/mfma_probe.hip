@@ -127,11 +127,12 @@ __global__ __launch_bounds__(512) void chunkloop(float* out, const float* __rest
                 typedef long long i64x2 __attribute__((ext_vector_type(2)));
                 const long long* rn = rows + ((c + 1) & 127) * 64 + 8 * s + 4 * h;
                 const i64x2 r01 = *reinterpret_cast<const i64x2*>(rn), r23 = *reinterpret_cast<const i64x2*>(rn + 2);
-                xn[4 * s + 0] = xcol[r01.x]; xn[4 * s + 1] = xcol[r01.y]; xn[4 * s + 2] = xcol[r23.x]; xn[4 * s + 3] = xcol[r23.y];
+                xn[4 * s + 0] = xcol[r01.x]; xn[4 * s + 1] = xcol[r01.y];
+                if (STEP != 17) { xn[4 * s + 2] = xcol[r23.x]; xn[4 * s + 3] = xcol[r23.y]; }      // STEP 17: half of the x loads
             }
             // STEP 5: all workgroups read the same slab rows; 6: loaded but not stored (the stores write stale registers);
             // 7: every workgroup its own rows (no sharing); 8: slab loads in the LAST four groups instead of the first four
-            if ((STEP == 5 || STEP == 7 || STEP == 11 || STEP == 14 || STEP == 15) && s < 4) sv[s] = *reinterpret_cast<const f32x4*>(a + ((int64_t)(((tid + 512 * s) >> 4) + (STEP == 7 ? (blockIdx.x % 3) * 128 : 0)) * lda + (c * 64 + 4 * (tid & 15)) % 1024));
+            if ((STEP == 5 || STEP == 7 || STEP == 11 || STEP == 14 || STEP == 15 || STEP == 17) && s < 4) sv[s] = *reinterpret_cast<const f32x4*>(a + ((int64_t)(((tid + 512 * s) >> 4) + (STEP == 7 ? (blockIdx.x % 3) * 128 : 0)) * lda + (c * 64 + 4 * (tid & 15)) % 1024));
             if (STEP == 9 && s < 4) sv[s] = *reinterpret_cast<const f32x4*>(a + ((int64_t)(((tid + 512 * s) >> 4) + blockIdx.x * 128) * lda + (c * 64 + 4 * (tid & 15)) % 1024));
             if (STEP == 10 && s < 4) sv[s] = *reinterpret_cast<const f32x4*>(a + ((int64_t)(((tid + 512 * s) >> 4) + (blockIdx.x & 7) * 128) * lda + (c * 64 + 4 * (tid & 15)) % 1024));
             if (STEP == 12 && s < 4) sv2[s] = *reinterpret_cast<const f32x4*>(a + ((int64_t)((tid + 512 * s) >> 4) * lda + (c * 64 + 4 * (tid & 15)) % 1024));
@@ -249,6 +250,7 @@ int main() {
         run_chunk<11>("  slab loads + stores, no x loads", 256, out, x, a, ldx, nrows);
         run_chunk<13>("  x + slab loads, slabs first in the chunk", 256, out, x, a, ldx, nrows);
         run_chunk<16>("  x + slab loads, slab stored a chunk after its loads", 256, out, x, a, ldx, nrows);
+        run_chunk<17>("  slab loads + HALF of the x loads (16 per chunk)", 256, out, x, a, ldx, nrows);
         run_chunk<14>("  x + slab loads, slab consumed by VALU only", 256, out, x, a, ldx, nrows);
         run_chunk<15>("  x + slab loads, vmcnt(0) before the stores", 256, out, x, a, ldx, nrows);
         run_chunk<12>("  x + slab loads, slab stored one chunk later", 256, out, x, a, ldx, nrows);
