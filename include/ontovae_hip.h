@@ -401,6 +401,16 @@ int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float* x, const 
 int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z, int32_t B, float* act_out,
                             int64_t act_ld, float* rec_out, int64_t rec_ld, void* stream);
 
+/* Backward of ontovae_decoder_forward plus the update of the masked operator: autograd of OntoDecoder.forward
+ * (onto_vae/modules.py:303-313) and of OntoEncoder.forward (modules.py:226-238: the same operator with the genes as its input
+ * and [mu | log_var] as its last layer), the gradient mask (onto_vae/vae_model.py:168-169, 611-616), AdamW (:172, :619) and the
+ * clamp of the weights at zero (:175-176, :622-625; biases are not clamped).  Must follow ontovae_decoder_forward on the same
+ * ctx and batch (the panel of that pass is read from the workspace).  drec [B, G] contiguous: dL/d(rec_out).
+ * apply_update != 0: AdamW + clamp in place; else the gradients of [dec_vals | dec_bias] go to ctx->Gr.
+ * dz_out [B, dz_ld >= L] or NULL: dL/dz. */
+int ontovae_decoder_backward(const ontovae_ctx_t* ctx, const float* drec, int32_t B, const ontovae_adamw_t* opt,
+                             int32_t apply_update, float* dz_out, int64_t dz_ld, void* stream);
+
 /* HBM-resident batcher helpers (replace onto_vae/fast_data_loader.py:33-34 on the device):
  * order_out[i] = order_in[perm[i]]  (the reference's cumulative in-place shuffle t[r]);
  * gather: out[b, :] = X[idx[b], :]. */
@@ -513,6 +523,22 @@ int ontovae_vae_train_step(const ontovae_vae_ctx_t* ctx, const float* x, const i
 int ontovae_vae_forward(const ontovae_vae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
                         uint64_t rng_offset, int32_t train, float kl_coeff, float* recon, float* mu, float* log_var, float* z_out,
                         float* loss_out, void* stream);
+/* OntoEncVAE (onto_vae/vae_model.py:468-905): ontology in the encoder, dense Decoder.  The masked encoder is
+ * ontovae_decoder_forward / ontovae_decoder_backward on a plan built from the encoder masks (input = the genes, last layer =
+ * the 2 Z head rows [mu; log_var]); these two entry points are everything between those calls.  The ctx is a dense VAE ctx
+ * whose decoder is the model's (its encoder side is a one-unit dummy that is never touched here).
+ * ontovae_vae_decode_forward: OntoEncVAE.forward after the encoder (vae_model.py:557-563) and, with loss_out, the rest of one
+ *   val_round body (:654-655).  heads [B, 2 Z] = [mu | log_var] before the heads' Dropout.  Outputs (any may be NULL):
+ *   recon [B, G], mu / log_var [B, Z] after that Dropout, z [B, Z]; loss_out: device float[3] {rec, kl, rec + kl_coeff kl}, needs x.
+ * ontovae_vae_decode_step: the middle of one train_round body (vae_model.py:603-619): reparameterisation, Decoder, ELBO,
+ *   backward down to the heads, AdamW of every decoder parameter (or gradients into ctx->Gr); dheads_out [B, 2 Z] is
+ *   dL/d(heads), what ontovae_decoder_backward takes as drec. */
+int ontovae_vae_decode_forward(const ontovae_vae_ctx_t* ctx, const float* heads, const float* x, const int32_t* xidx, int32_t B,
+                               const float* eps, uint64_t rng_offset, int32_t train, float kl_coeff, float* recon, float* mu,
+                               float* log_var, float* z_out, float* loss_out, void* stream);
+int ontovae_vae_decode_step(const ontovae_vae_ctx_t* ctx, const float* heads, const float* x, const int32_t* xidx, int32_t B,
+                            const float* eps, uint64_t rng_offset, float kl_coeff, const ontovae_adamw_t* opt, int32_t apply_update,
+                            float* dheads_out, float* loss_out, void* stream);
 /* torch.optim.AdamW.step over the flat buffers with gradients from ctx->Gr (after apply_update == 0). */
 int ontovae_vae_adamw_apply(const ontovae_vae_ctx_t* ctx, const ontovae_adamw_t* opt, void* stream);
 

@@ -278,6 +278,28 @@ static int ov_vae_block_fwd(OvVaeStep& s, const OvVaeLayer& l, const float* prev
     return ONTOVAE_OK;
 }
 
+// dense Decoder (modules.py:116-153) on ws.z: blocks, then the output layer; leaves recon (with bias) in ws.rec
+static int ov_vae_decoder_fwd(OvVaeStep& s, int train) {
+    const ontovae_vae_ctx_t* c = s.c;
+    const OvVaeNet& n = s.n;
+    int rc;
+    const float* prev = s.ws.z;
+    for (int i = 0; i < n.nd; ++i) {
+        OvVaeLayer l = n.dec[i];
+        if ((rc = ov_vae_block_fwd(s, l, prev, train))) return rc;
+        prev = s.ws.a[l.bn_index];
+    }
+    // output layer: recon = Wout a + bout (modules.py:127-131), feature-major
+    const int Hd = n.dec[n.nd - 1].out;
+    OvGemm g{};
+    g.M = n.G; g.N = s.B; g.K = Hd;
+    g.A = c->P + n.Wout; g.lda = Hd;
+    g.B = prev; g.ldb = s.ldb;
+    g.C = s.ws.rec; g.ldc = s.ldb; g.slab_stride = 0; g.kchunk = (Hd + 31) / 32 * 32;
+    g.bias = c->P + n.bout;
+    return ov_launch_gemm<1, 1, 4, 4, true, false, OV_EPI_BIAS>(g, 1, (Hd % 4 == 0) && ov_al16(g.A), s.st);
+}
+
 // encoder + heads + reparameterisation + decoder; leaves recon (with bias) in ws.rec, mu / log_var in ws.mulv, z in ws.z
 // encoder_only: stop after the reparameterisation (Encoder.forward / get_embedding, modules.py:74-84, vae_model.py:970-981: the
 // reference runs no decoder there, so the decoder's BatchNorm buffers must not move in train mode)
@@ -311,21 +333,7 @@ static int ov_vae_forward_core(OvVaeStep& s, const float* eps, int train, int wr
         if (nkl) *nkl = blocks;
     }
     if (encoder_only) return ONTOVAE_OK;
-    prev = s.ws.z;
-    for (int i = 0; i < n.nd; ++i) {
-        OvVaeLayer l = n.dec[i];
-        if ((rc = ov_vae_block_fwd(s, l, prev, train))) return rc;
-        prev = s.ws.a[l.bn_index];
-    }
-    // output layer: recon = Wout a + bout (modules.py:127-131), feature-major
-    const int Hd = n.dec[n.nd - 1].out;
-    OvGemm g{};
-    g.M = n.G; g.N = s.B; g.K = Hd;
-    g.A = c->P + n.Wout; g.lda = Hd;
-    g.B = prev; g.ldb = s.ldb;
-    g.C = s.ws.rec; g.ldc = s.ldb; g.slab_stride = 0; g.kchunk = (Hd + 31) / 32 * 32;
-    g.bias = c->P + n.bout;
-    return ov_launch_gemm<1, 1, 4, 4, true, false, OV_EPI_BIAS>(g, 1, (Hd % 4 == 0) && ov_al16(g.A), s.st);
+    return ov_vae_decoder_fwd(s, train);
 }
 
 static int ov_vae_loss(OvVaeStep& s, int* nrec) {
@@ -400,21 +408,13 @@ static int ov_vae_block_bwd(OvVaeStep& s, const OvVaeLayer& l, const float* ga, 
     return ov_vae_dw(s, l.W, l.out, l.in, s.ws.dh, prev);
 }
 
-extern "C" int ontovae_vae_train_step(const ontovae_vae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
-                                      uint64_t rng_offset, float kl_coeff, const ontovae_adamw_t* opt, int32_t apply_update,
-                                      float* loss_out, void* stream) {
-    OvVaeStep s;
-    int rc = ov_vae_check(ctx, B, apply_update != 0, &s, x, xidx, stream);
-    if (rc) return rc;
-    if (!loss_out) { ontovae_set_error("vae_train_step: loss_out is NULL"); return ONTOVAE_EINVAL; }
-    if (apply_update && !opt) { ontovae_set_error("vae_train_step: opt is NULL"); return ONTOVAE_EINVAL; }
-    if (!apply_update && !ctx->Gr) { ontovae_set_error("vae_train_step: gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
-    if (B < 2) { ontovae_set_error("vae_train_step: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
-    s.adam = ov_adam_from(opt); s.apply = apply_update ? 1 : 0; s.rng_off = rng_offset;
+// loss and the backward of the dense Decoder: sum-of-squares partials (nrec of them), every decoder parameter's gradient
+// (+ AdamW), dL/dz in ws.dz
+static int ov_vae_decoder_bwd(OvVaeStep& s, int* nrec) {
+    const ontovae_vae_ctx_t* ctx = s.c;
     const OvVaeNet& n = s.n;
-    int nkl = 0, nrec = 0;
-    if ((rc = ov_vae_forward_core(s, eps, 1, 1, &nkl))) return rc;
-    if ((rc = ov_vae_loss(s, &nrec))) return rc;                    // ws.rec now holds dL/drecon
+    int rc;
+    if ((rc = ov_vae_loss(s, nrec))) return rc;                     // ws.rec now holds dL/drecon
     // output layer: bias gradient, da (before the weights move), dW
     hipLaunchKernelGGL(ov_vae_rowsum_kernel, dim3((n.G + 3) / 4), dim3(256), 0, s.st, s.ws.rec, n.G, s.B, s.ldb, ctx->P + n.bout,
                        ctx->M ? ctx->M + n.bout : nullptr, ctx->V ? ctx->V + n.bout : nullptr, ctx->Gr ? ctx->Gr + n.bout : nullptr, s.apply,
@@ -432,6 +432,25 @@ extern "C" int ontovae_vae_train_step(const ontovae_vae_ctx_t* ctx, const float*
         if ((rc = ov_vae_block_bwd(s, l, s.ws.ga, daS, prev, i > 0 ? s.ws.ga : s.ws.dz, &S2, i > 0))) return rc;
         daS = S2;
     }
+    return ONTOVAE_OK;
+}
+
+extern "C" int ontovae_vae_train_step(const ontovae_vae_ctx_t* ctx, const float* x, const int32_t* xidx, int32_t B, const float* eps,
+                                      uint64_t rng_offset, float kl_coeff, const ontovae_adamw_t* opt, int32_t apply_update,
+                                      float* loss_out, void* stream) {
+    OvVaeStep s;
+    int rc = ov_vae_check(ctx, B, apply_update != 0, &s, x, xidx, stream);
+    if (rc) return rc;
+    if (!loss_out) { ontovae_set_error("vae_train_step: loss_out is NULL"); return ONTOVAE_EINVAL; }
+    if (apply_update && !opt) { ontovae_set_error("vae_train_step: opt is NULL"); return ONTOVAE_EINVAL; }
+    if (!apply_update && !ctx->Gr) { ontovae_set_error("vae_train_step: gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+    if (B < 2) { ontovae_set_error("vae_train_step: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
+    s.adam = ov_adam_from(opt); s.apply = apply_update ? 1 : 0; s.rng_off = rng_offset;
+    const OvVaeNet& n = s.n;
+    int nkl = 0, nrec = 0;
+    if ((rc = ov_vae_forward_core(s, eps, 1, 1, &nkl))) return rc;
+    if ((rc = ov_vae_decoder_bwd(s, &nrec))) return rc;
+    int daS = 1;
     {
         OvLatentArgs la{s.ws.dz, s.ws.mulv, s.ws.epsw, s.ws.dmulv, n.Z, s.B, s.ldb, kl_coeff, ctx->z_drop, ctx->seed, rng_offset,
                         ctx->P + n.bh, ctx->M ? ctx->M + n.bh : nullptr, ctx->V ? ctx->V + n.bh : nullptr, ctx->Gr ? ctx->Gr + n.bh : nullptr,
@@ -480,6 +499,98 @@ extern "C" int ontovae_vae_forward(const ontovae_vae_ctx_t* ctx, const float* x,
         OV_LAUNCH_CHECK();
     }
     return ONTOVAE_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// OntoEncVAE (reference vae_model.py:468-905): the ontology sits in the ENCODER (OntoEncoder, modules.py:161-238: masked
+// linear layers with prepending concatenation and two masked heads over the whole concatenation, no BatchNorm, no ReLU)
+// and the decoder is the dense Decoder above.  The masked encoder is the same sparse operator as OntoDecoder with the genes
+// as its input: ontovae_decoder_forward / ontovae_decoder_backward on a plan built from the encoder masks give the heads
+// [B, 2 Z] = [mu | log_var] and take their gradient.  The two entry points here are everything between those two calls.
+// (The dense ctx keeps a one-unit dummy encoder; its parameters are never touched here.)
+// -------------------------------------------------------------------------------------------------
+// heads [B, 2 Z] sample-major -> ws.mulv (after z_drop in train mode), eps, z, KL partials
+static int ov_vae_heads_in(OvVaeStep& s, const float* heads, const float* eps, int train, int write_kl, int* nkl) {
+    const ontovae_vae_ctx_t* c = s.c;
+    const OvVaeNet& n = s.n;
+    dim3 grid((2 * n.Z + 31) / 32, (s.ldb + 31) / 32);
+    hipLaunchKernelGGL(ov_transpose_in_kernel, grid, dim3(256), 0, s.st, heads, 2 * n.Z, s.B, s.ldb, s.ws.slab);
+    OV_LAUNCH_CHECK();
+    OV_HIP_CHECK(hipMemsetAsync(s.ws.dmulv, 0, 2 * (size_t)n.Z * sizeof(float), s.st));      // the heads carry their biases already
+    const int64_t cnt = (int64_t)n.Z * s.ldb;
+    const int blocks = (int)std::min<int64_t>((cnt + 255) / 256, std::min<int64_t>(2048, s.ws.npart));
+    OvRefresh rf{};
+    hipLaunchKernelGGL(ov_reparam_kernel, dim3(blocks), dim3(256), 0, s.st, s.ws.mulv, eps, train ? s.ws.epsw : (float*)nullptr, s.ws.z,
+                       s.ws.kl_part, n.Z, s.B, s.ldb, train, c->z_drop, c->seed, s.rng_off, (uint32_t)OV_RNG_EPS, write_kl, blocks, rf,
+                       (const float*)s.ws.slab, 1, 2LL * n.Z * s.ldb, (const float*)s.ws.dmulv);
+    OV_LAUNCH_CHECK();
+    if (nkl) *nkl = blocks;
+    return ONTOVAE_OK;
+}
+
+// OntoEncVAE.forward after the encoder (vae_model.py:557-563) and, with loss_out, the rest of one val_round body (:654-655).
+// heads: [B, 2 Z] = [mu | log_var] as OntoEncoder's two Linear layers give them (before their Dropout).  Outputs (any may be
+// NULL): recon [B, G], mu / log_var [B, Z] after the heads' Dropout, z [B, Z]; loss_out: device float[3], needs x.
+extern "C" int ontovae_vae_decode_forward(const ontovae_vae_ctx_t* ctx, const float* heads, const float* x, const int32_t* xidx,
+                                          int32_t B, const float* eps, uint64_t rng_offset, int32_t train, float kl_coeff, float* recon,
+                                          float* mu, float* log_var, float* z_out, float* loss_out, void* stream) {
+    OvVaeStep s;
+    if (!heads) { ontovae_set_error("vae_decode_forward: heads is NULL"); return ONTOVAE_EINVAL; }
+    if (loss_out && !x) { ontovae_set_error("vae_decode_forward: the loss needs x"); return ONTOVAE_EINVAL; }
+    int rc = ov_vae_check(ctx, B, false, &s, x ? x : heads, xidx, stream);
+    if (rc) return rc;
+    if (train && B < 2) { ontovae_set_error("vae_decode_forward: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
+    s.rng_off = rng_offset;
+    const OvVaeNet& n = s.n;
+    int nkl = 0, nrec = 0;
+    if ((rc = ov_vae_heads_in(s, heads, eps, train ? 1 : 0, loss_out ? 1 : 0, &nkl))) return rc;
+    if ((recon || loss_out) && (rc = ov_vae_decoder_fwd(s, train ? 1 : 0))) return rc;
+    OvStep t{};
+    t.B = B; t.ldb = s.ldb; t.st = s.st;
+    if (recon && (rc = ov_transpose_out(t, s.ws.rec, n.G, recon, n.G))) return rc;
+    if (mu && (rc = ov_transpose_out(t, s.ws.mulv, n.Z, mu, n.Z))) return rc;
+    if (log_var && (rc = ov_transpose_out(t, s.ws.mulv + (int64_t)n.Z * s.ldb, n.Z, log_var, n.Z))) return rc;
+    if (z_out && (rc = ov_transpose_out(t, s.ws.z, n.Z, z_out, n.Z))) return rc;
+    if (loss_out) {
+        if ((rc = ov_vae_loss(s, &nrec))) return rc;
+        hipLaunchKernelGGL(ov_loss_finalize_kernel, dim3(1), dim3(1024), 0, s.st, s.ws.rec_part, nrec, s.ws.kl_part, nkl, kl_coeff, loss_out);
+        OV_LAUNCH_CHECK();
+    }
+    return ONTOVAE_OK;
+}
+
+// The middle of one OntoEncVAE.train_round body (vae_model.py:603-619): reparameterisation, dense Decoder, ELBO, backward down
+// to the heads, AdamW of every decoder parameter (apply_update) or their gradients into ctx->Gr.
+// dheads_out [B, 2 Z]: dL/d[mu | log_var] at the heads' Linear outputs -- what ontovae_decoder_backward takes.
+extern "C" int ontovae_vae_decode_step(const ontovae_vae_ctx_t* ctx, const float* heads, const float* x, const int32_t* xidx, int32_t B,
+                                       const float* eps, uint64_t rng_offset, float kl_coeff, const ontovae_adamw_t* opt,
+                                       int32_t apply_update, float* dheads_out, float* loss_out, void* stream) {
+    OvVaeStep s;
+    if (!heads || !dheads_out || !loss_out) { ontovae_set_error("vae_decode_step: heads, dheads_out or loss_out is NULL"); return ONTOVAE_EINVAL; }
+    int rc = ov_vae_check(ctx, B, apply_update != 0, &s, x, xidx, stream);
+    if (rc) return rc;
+    if (apply_update && !opt) { ontovae_set_error("vae_decode_step: opt is NULL"); return ONTOVAE_EINVAL; }
+    if (!apply_update && !ctx->Gr) { ontovae_set_error("vae_decode_step: gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+    if (B < 2) { ontovae_set_error("vae_decode_step: BatchNorm in train mode needs more than 1 sample per batch"); return ONTOVAE_EINVAL; }
+    s.adam = ov_adam_from(opt); s.apply = apply_update ? 1 : 0; s.rng_off = rng_offset;
+    const OvVaeNet& n = s.n;
+    int nkl = 0, nrec = 0;
+    if ((rc = ov_vae_heads_in(s, heads, eps, 1, 1, &nkl))) return rc;
+    if ((rc = ov_vae_decoder_fwd(s, 1))) return rc;
+    if ((rc = ov_vae_decoder_bwd(s, &nrec))) return rc;
+    {
+        // the heads' biases belong to the masked operator: their gradient (row sums of dmulv) goes to scratch here
+        OvLatentArgs la{s.ws.dz, s.ws.mulv, s.ws.epsw, s.ws.dmulv, n.Z, s.B, s.ldb, kl_coeff, ctx->z_drop, ctx->seed, rng_offset,
+                        nullptr, nullptr, nullptr, s.ws.bwd_local, 0, s.adam,
+                        OvLossArgs{s.ws.rec_part, nrec, s.ws.kl_part, nkl, kl_coeff, loss_out}, n.Z + 1};
+        OvWgradArgs none{};
+        OvFinishArgs nofin{};
+        hipLaunchKernelGGL(ov_latent_bwd_kernel, dim3(la.nblocks), dim3(256), 0, s.st, la, none, 0, nofin, 0);
+        OV_LAUNCH_CHECK();
+    }
+    OvStep t{};
+    t.B = B; t.ldb = s.ldb; t.st = s.st;
+    return ov_transpose_out(t, s.ws.dmulv, 2 * n.Z, dheads_out, 2 * n.Z);
 }
 
 // torch.optim.AdamW.step over the flat buffers (vae_model.py:1101), gradients from ctx->Gr: the unfused path

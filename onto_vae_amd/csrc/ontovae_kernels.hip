@@ -3614,6 +3614,44 @@ extern "C" int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z,
     return ONTOVAE_OK;
 }
 
+// Backward of ontovae_decoder_forward and the update of the masked operator: autograd of OntoDecoder.forward
+// (modules.py:303-313) / OntoEncoder.forward (modules.py:226-238), the gradient mask (vae_model.py:168-169, 611-616: implicit,
+// only mask positions exist), AdamW (vae_model.py:172, 619) and the clamp of the weights at zero (vae_model.py:175-176,
+// 622-625; biases are not clamped).  Must follow ontovae_decoder_forward on the same ctx and batch: the panel of that pass is
+// read from the workspace.  drec [B, G] sample-major, contiguous: dL/d(rec_out).  apply_update != 0: AdamW + clamp in place
+// (opt, ctx->M, ctx->V required); else the gradients of [dec_vals | dec_bias] go to ctx->Gr.  dz_out [B, L] (may be NULL):
+// dL/dz.  The general-purpose kernels (one wave per row for the weight gradient): this entry point is for models whose
+// ontology sits in the encoder (OntoEncVAE), not for the OntoVAE step, which has its own fused path.
+extern "C" int ontovae_decoder_backward(const ontovae_ctx_t* ctx, const float* drec, int32_t B, const ontovae_adamw_t* opt,
+                                        int32_t apply_update, float* dz_out, int64_t dz_ld, void* stream) {
+    int rc = ov_check_ctx(ctx, B, apply_update != 0, true);
+    if (rc) return rc;
+    if (!drec) { ontovae_set_error("decoder_backward: drec is NULL"); return ONTOVAE_EINVAL; }
+    if (apply_update && !opt) { ontovae_set_error("decoder_backward: opt is NULL"); return ONTOVAE_EINVAL; }
+    if (!apply_update && !ctx->Gr) { ontovae_set_error("decoder_backward: gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_dims_t& d = ctx->dims;
+    const ontovae_layout_t& lay = ctx->lay;
+    if (dz_out && dz_ld < d.L) { ontovae_set_error("decoder_backward: dz leading dimension too small"); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, nullptr, nullptr, B, stream, &s);
+    // dL/d(rec) into the gene rows of D, feature-major, zeros in the padded columns
+    dim3 grid((d.G + 31) / 32, (s.ldb + 31) / 32);
+    hipLaunchKernelGGL(ov_transpose_in_kernel, grid, dim3(256), 0, s.st, drec, d.G, B, s.ldb, s.ws.d + (int64_t)d.C * s.ldb);
+    OV_LAUNCH_CHECK();
+    if ((rc = ov_dec_backward(s))) return rc;
+    const OvAdam adam = ov_adam_from(opt);
+    const int n_term_rows = d.C - d.L, wrows = n_term_rows + d.G;
+    float* G_ = ctx->Gr;
+    hipLaunchKernelGGL(ov_dec_wgrad_kernel, dim3((wrows + 3) / 4), dim3(256), 0, s.st, ctx->rowptr, ctx->colidx, ctx->row_k, s.ws.act, s.ws.d,
+                       ctx->P + lay.dec_vals, ctx->M ? ctx->M + lay.dec_vals : nullptr, ctx->V ? ctx->V + lay.dec_vals : nullptr,
+                       G_ ? G_ + lay.dec_vals : nullptr, ctx->P + lay.dec_bias, ctx->M ? ctx->M + lay.dec_bias : nullptr,
+                       ctx->V ? ctx->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, wrows, 0, n_term_rows, d.C, s.ldb,
+                       apply_update ? 1 : 0, adam);
+    OV_LAUNCH_CHECK();
+    if (dz_out && (rc = ov_transpose_out(s, s.ws.d + (int64_t)(d.C - d.L) * s.ldb, d.L, dz_out, dz_ld))) return rc;
+    return ONTOVAE_OK;
+}
+
 // =================================================================================================
 // C ABI: training
 // =================================================================================================

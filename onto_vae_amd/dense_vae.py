@@ -188,6 +188,44 @@ class DenseEngine:
     def eval_step(self, x, xidx, eps, kl_coeff, loss_out):
         self.forward(x, xidx, eps, train=False, want=(), kl_coeff=kl_coeff, loss_out=loss_out)
 
+    # ---- OntoEncVAE: the masked encoder's heads come in, their gradient goes out (ontovae_vae_decode_forward / _step)
+    def _heads(self, heads):
+        if heads.dim() != 2 or heads.shape[1] != 2 * self.Z or heads.dtype != torch.float32 or not heads.is_contiguous() or heads.device != self.device:
+            raise ValueError(f"heads must be a contiguous float32 [B, {2 * self.Z}] tensor on the model's device")
+        return heads, heads.shape[0]
+
+    @_on_device
+    def decode_forward(self, heads, x=None, xidx=None, eps=None, train=False, want=("recon", "mu", "log_var"), kl_coeff=0.0, loss_out=None):
+        heads, B = self._heads(heads)
+        if x is not None:
+            x, xidx, Bx = self._x(x, xidx)
+            if Bx != B:
+                raise ValueError("heads and x disagree on the batch size")
+        eps = self._eps(eps, B)
+        width = dict(recon=self.G, mu=self.Z, log_var=self.Z, z=self.Z)
+        out = {k: (torch.empty(B, width[k], dtype=torch.float32, device=self.device) if k in want else None) for k in width}
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_vae_decode_forward(C.byref(ctx), _ptr(heads), _ptr(x), _ptr(xidx), B, _ptr(eps), self.next_offset(),
+                                                         1 if train else 0, float(kl_coeff), _ptr(out["recon"]), _ptr(out["mu"]),
+                                                         _ptr(out["log_var"]), _ptr(out["z"]), _ptr(loss_out), self.stream()), "vae_decode_forward")
+        return out
+
+    @_on_device
+    def decode_step(self, heads, x, xidx, eps, kl_coeff, adam, dheads_out, loss_out, apply_update=True):
+        heads, B = self._heads(heads)
+        x, xidx, Bx = self._x(x, xidx)
+        if Bx != B:
+            raise ValueError("heads and x disagree on the batch size")
+        eps = self._eps(eps, B)
+        if apply_update:
+            self.ensure_opt_state()
+        else:
+            self.ensure_grad_buffer()
+        ctx = self.ctx(B)
+        _lib.check(_lib.lib().ontovae_vae_decode_step(C.byref(ctx), _ptr(heads), _ptr(x), _ptr(xidx), B, _ptr(eps), self.next_offset(),
+                                                      float(kl_coeff), C.byref(adam) if adam is not None else None, 1 if apply_update else 0,
+                                                      _ptr(dheads_out), _ptr(loss_out), self.stream()), "vae_decode_step")
+
     @_on_device
     def adamw_apply(self, adam):
         self.ensure_opt_state()

@@ -473,13 +473,31 @@ class Engine:
             rec_out.stride(0) if rec_out is not None else 0, self.stream()), "pass_data_perturbed")
 
     @_on_device
-    def decoder_forward(self, z, act_out=None, rec_out=None):
+    def decoder_forward(self, z, act_out=None, rec_out=None, train=False):
+        """train: the pass is followed by decoder_backward on the same batch (sizes the training buffers of the workspace)."""
         z = torch.as_tensor(z, dtype=torch.float32, device=self.device).contiguous()
         if z.dim() != 2 or z.shape[1] != self.plan.L:
             raise ValueError(f"expected z of shape [B, {self.plan.L}]")
         B = z.shape[0]
-        ctx = self.ctx(B)
+        ctx = self.ctx(B, train=train)
         _lib.check(_lib.lib().ontovae_decoder_forward(C.byref(ctx), _ptr(z), B, _ptr(act_out),
                                                       act_out.stride(0) if act_out is not None else 0, _ptr(rec_out),
                                                       rec_out.stride(0) if rec_out is not None else 0, self.stream()),
                    "decoder_forward")
+
+    @_on_device
+    def decoder_backward(self, drec, adam, apply_update=True, dz_out=None):
+        """ontovae_decoder_backward: gradient of the masked operator for the batch decoder_forward(train=True) just ran, AdamW +
+        clamp(0) in place (or gradients into Gr), optionally dL/dz."""
+        drec = torch.as_tensor(drec, dtype=torch.float32, device=self.device).contiguous()
+        if drec.dim() != 2 or drec.shape[1] != self.plan.G:
+            raise ValueError(f"expected drec of shape [B, {self.plan.G}]")
+        B = drec.shape[0]
+        if apply_update:
+            self.ensure_opt_state()
+        else:
+            self.ensure_grad_buffer()
+        ctx = self.ctx(B, train=True)
+        _lib.check(_lib.lib().ontovae_decoder_backward(C.byref(ctx), _ptr(drec), B, C.byref(adam) if adam is not None else None,
+                                                       1 if apply_update else 0, _ptr(dz_out),
+                                                       dz_out.stride(0) if dz_out is not None else 0, self.stream()), "decoder_backward")
