@@ -530,3 +530,12 @@ class OntoVAE(nn.Module):
 
 
 from .dense_vae import VAE  # noqa: E402,F401  (reference vae_model.py:913: the plain VAE lives in the same module)
+
+
+def __getattr__(name):
+    """OntoEncVAE lives in vae_model.py upstream (reference vae_model.py:468); here it is imported on first use (its module
+    imports this one)."""
+    if name == "OntoEncVAE":
+        from .enc_vae_model import OntoEncVAE
+        return OntoEncVAE
+    raise AttributeError(name)
