@@ -401,14 +401,20 @@ int ontovae_pass_data_perturbed(const ontovae_ctx_t* ctx, const float* x, const 
 int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z, int32_t B, float* act_out,
                             int64_t act_ld, float* rec_out, int64_t rec_ld, void* stream);
 
-/* Backward of ontovae_decoder_forward plus the update of the masked operator: autograd of OntoDecoder.forward
+/* ontovae_decoder_forward for a TRAINING pass of a model whose ontology sits in the encoder (OntoEncVAE): Dropout(ctx->drop)
+ * on the output of every term layer -- OntoEncoder's [Linear, Dropout] blocks, onto_vae/modules.py:219-223, 231-233 -- keyed by
+ * rng_offset (Philox, like every other dropout of the library); the last layer (the heads) carries none here, their
+ * Dropout(z_drop) belongs to ontovae_vae_decode_step.  ctx->drop == 0: the same as ontovae_decoder_forward. */
+int ontovae_decoder_forward_train(const ontovae_ctx_t* ctx, const float* z, int32_t B, uint64_t rng_offset, float* rec_out,
+                                  int64_t rec_ld, void* stream);
+/* Backward of ontovae_decoder_forward[_train] plus the update of the masked operator: autograd of OntoDecoder.forward
  * (onto_vae/modules.py:303-313) and of OntoEncoder.forward (modules.py:226-238: the same operator with the genes as its input
  * and [mu | log_var] as its last layer), the gradient mask (onto_vae/vae_model.py:168-169, 611-616), AdamW (:172, :619) and the
- * clamp of the weights at zero (:175-176, :622-625; biases are not clamped).  Must follow ontovae_decoder_forward on the same
- * ctx and batch (the panel of that pass is read from the workspace).  drec [B, G] contiguous: dL/d(rec_out).
- * apply_update != 0: AdamW + clamp in place; else the gradients of [dec_vals | dec_bias] go to ctx->Gr.
- * dz_out [B, dz_ld >= L] or NULL: dL/dz. */
-int ontovae_decoder_backward(const ontovae_ctx_t* ctx, const float* drec, int32_t B, const ontovae_adamw_t* opt,
+ * clamp of the weights at zero (:175-176, :622-625; biases are not clamped).  Must follow the forward call on the same ctx and
+ * batch (the panel of that pass is read from the workspace) with the same rng_offset (ctx->drop > 0: the same dropout masks).
+ * drec [B, G] contiguous: dL/d(rec_out).  apply_update != 0: AdamW + clamp in place; else the gradients of
+ * [dec_vals | dec_bias] go to ctx->Gr.  dz_out [B, dz_ld >= L] or NULL: dL/dz. */
+int ontovae_decoder_backward(const ontovae_ctx_t* ctx, const float* drec, int32_t B, uint64_t rng_offset, const ontovae_adamw_t* opt,
                              int32_t apply_update, float* dz_out, int64_t dz_ld, void* stream);
 
 /* HBM-resident batcher helpers (replace onto_vae/fast_data_loader.py:33-34 on the device):

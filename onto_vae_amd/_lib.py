@@ -148,7 +148,8 @@ def lib():
         "ontovae_vae_adamw_apply": [C.POINTER(VaeCtx), C.POINTER(AdamW), vp],
         "ontovae_vae_decode_forward": [C.POINTER(VaeCtx), vp, vp, vp, i32, vp, u64, i32, f32, vp, vp, vp, vp, vp, vp],
         "ontovae_vae_decode_step": [C.POINTER(VaeCtx), vp, vp, vp, i32, vp, u64, f32, C.POINTER(AdamW), i32, vp, vp, vp],
-        "ontovae_decoder_backward": [C.POINTER(Ctx), vp, i32, C.POINTER(AdamW), i32, vp, i64, vp],
+        "ontovae_decoder_backward": [C.POINTER(Ctx), vp, i32, u64, C.POINTER(AdamW), i32, vp, i64, vp],
+        "ontovae_decoder_forward_train": [C.POINTER(Ctx), vp, i32, u64, vp, i64, vp],
         "ontovae_profile_begin": [C.c_uint32, i32],
         "ontovae_profile_read": [i32, c_f32p, i32, c_i32p],
         "ontovae_profile_end": [],
@@ -184,7 +185,7 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_wilcoxon_workspace_bytes", "ontovae_wilcoxon_zsplit", "ontovae_fdr_workspace_bytes", "ontovae_fdr_bh", "ontovae_fdr_bh_static",
             "ontovae_to_feature_major",
             "ontovae_vae_layout", "ontovae_vae_workspace_bytes", "ontovae_vae_train_step", "ontovae_vae_forward", "ontovae_vae_adamw_apply",
-            "ontovae_vae_decode_forward", "ontovae_vae_decode_step", "ontovae_decoder_backward",
+            "ontovae_vae_decode_forward", "ontovae_vae_decode_step", "ontovae_decoder_backward", "ontovae_decoder_forward_train",
             "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end", "ontovae_profile_overhead"]
 
 FLAG_BF16_GEMM = 32

@@ -846,6 +846,12 @@ __global__ __launch_bounds__(256) void ov_dec_fwd_term_kernel(const int32_t* __r
     }
 }
 
+// Dropout on the outputs of the term layers (OntoEncoder's [Linear, Dropout] blocks, modules.py:219-223; OntoDecoder has none):
+// rate 0 = off.  The keep-scale of (node, batch column) comes from the Philox stream OV_RNG_DROP of (seed, rng_off); the forward
+// level kernel multiplies a node's output by it, the backward level kernel the finished gradient row of the node, so that
+// everything below (the children's gradients, the node's own weight gradient) sees the gradient at the Linear's output.
+struct OvTermDrop { float rate; uint64_t seed, rng_off; };
+
 // GENE: 0 = term level (write ACT), 1 = gene level training (D + loss partials), 2 = gene level
 // inference (recon sample-major to rec_out)
 template <int VEC, int GENE>
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(256) void ov_dec_fwd_kernel(const int32_t* __restri
                                                         float* __restrict__ act, int node_begin, int node_end, int B, int ldb,
                                                         const float* __restrict__ x, const int32_t* __restrict__ xidx, int G,
                                                         float* __restrict__ d, float* __restrict__ rec_part,
-                                                        float* __restrict__ rec_out, int64_t rec_ld, int C) {
+                                                        float* __restrict__ rec_out, int64_t rec_ld, int C, const OvTermDrop dr) {
     const int node = node_begin + blockIdx.x * 4 + ov_wave_id();
     const int lane = ov_lane();
     const int b0 = blockIdx.y * (64 * VEC) + lane * VEC;
@@ -891,6 +897,11 @@ __global__ __launch_bounds__(256) void ov_dec_fwd_kernel(const int32_t* __restri
             for (int j = 0; j < VEC; ++j) acc[j] += w0 * v0[j];
         }
         if (GENE == 0) {
+            if (dr.rate > 0.f) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    acc[j] *= ov_dropout_scale(dr.rate, dr.seed, dr.rng_off, OV_RNG_DROP, (uint64_t)node * 0x100000000ull + (uint64_t)(b0 + j));
+            }
             ov_stv<VEC>(act + (int64_t)node * ldb + b0, acc);
         } else if (GENE == 1) {
             const int g = node - C;
@@ -2022,7 +2033,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_row,
                                                         const int32_t* __restrict__ csc_k, const float* __restrict__ vals,
                                                         float* __restrict__ d, int node_begin, int node_end, int ldb,
-                                                        const int32_t* __restrict__ csc_split) {
+                                                        const int32_t* __restrict__ csc_split, const OvTermDrop dr, int n_drop) {
     const int node = node_begin + blockIdx.x * 4 + ov_wave_id();
     if (node >= node_end) return;
     const int b0 = blockIdx.y * (64 * VEC) + ov_lane() * VEC;
@@ -2058,6 +2069,11 @@ __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restri
         ov_ldv<VEC>(d + (int64_t)r0 * ldb + b0, v0);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] += w0 * v0[j];
+    }
+    if (dr.rate > 0.f && node < n_drop) {        // term nodes only: the rows of the operator's input carry no dropout
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            acc[j] *= ov_dropout_scale(dr.rate, dr.seed, dr.rng_off, OV_RNG_DROP, (uint64_t)node * 0x100000000ull + (uint64_t)(b0 + j));
     }
     ov_stv<VEC>(d + (int64_t)node * ldb + b0, acc);
 }
@@ -2796,6 +2812,7 @@ struct OvStep {
     // (bias partials in the forward kernel, link partials in the backward kernel); NULL = not wanted
     float* gw_part; float* gw_bpart; int gw_rows, gw_row0;
     bool gene_lds;           // the gene layer's forward of this pass is ov_gene_lds_kernel (entry points that compute the loss set it)
+    OvTermDrop tdrop;        // dropout on the term layers' outputs (OntoEncoder training passes); rate 0 everywhere else
 };
 
 // Independent branches of a step run on a library-owned second stream, forked from and joined back into
@@ -2965,6 +2982,7 @@ static int ov_fused_bt(const ontovae_ctx_t* c);
 // (25 us on a fraction of the chip) instead of in front of it
 static bool ov_gene_refresh_rides(const OvStep& s) {
     const int bt = ov_fused_bt(s.c);
+    if (s.tdrop.rate > 0.f) return false;       // term-layer dropout: per-level kernels, no chain launch to ride in
     return bt != 0 && s.ldb / bt <= 128;        // the chain and its replicas leave half of the CUs to riders
 }
 static void ov_gene_refresh_args(const OvStep& s, OvRefresh* r) {
@@ -3023,7 +3041,7 @@ static int ov_dec_fwd_level(OvStep& s, int nb, int ne, float* rec_out, int64_t r
     const float* vals = GENE ? s.ws.wgene - d.nnz_term : c->P + c->lay.dec_vals;
     const float* bias = c->P + c->lay.dec_bias;
     OvProfScope prof(GENE ? ONTOVAE_PHASE_DEC_FWD_GENE : ONTOVAE_PHASE_DEC_FWD_TERMS, s.st);
-    if (GENE == 0 && s.fm_out) {          // ov_fm_fused(s) held: see ontovae_pass_data_perturbed
+    if (GENE == 0 && s.fm_out && s.tdrop.rate <= 0.f) {          // ov_fm_fused(s) held: see ontovae_pass_data_perturbed
         int c_base = 0;
         for (int lvl = 0; lvl < d.K && c->level_begin[lvl] != nb; ++lvl) c_base += (c->level_end[lvl] - c->level_begin[lvl]) / d.nu;
         const dim3 tgrid(((ne - nb) / d.nu + 3) / 4, s.nchunk);
@@ -3035,7 +3053,7 @@ static int ov_dec_fwd_level(OvStep& s, int nb, int ne, float* rec_out, int64_t r
     }
 #define OV_DF(V)                                                                                                        \
     hipLaunchKernelGGL((ov_dec_fwd_kernel<V, GENE>), grid, dim3(256), 0, s.st, c->rowptr, c->colidx, vals, bias, s.ws.act, \
-                       nb, ne, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C)
+                       nb, ne, s.B, s.ldb, s.x, s.xidx, d.G, s.ws.d, s.ws.rec_part, rec_out, rec_ld, d.C, s.tdrop)
     if (s.vec == 1) OV_DF(1); else if (s.vec == 2) OV_DF(2); else OV_DF(4);
 #undef OV_DF
     OV_LAUNCH_CHECK();
@@ -3089,7 +3107,8 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     // The chain kernel keeps a [C][bt] panel in LDS, so a workgroup carries 4 columns and a large batch becomes many rounds
     // of latency-bound workgroups; from 2048 columns on one launch per level over the whole batch is faster
     // (B = 4096: 121 us against 203 us; B = 1024: 75 against 51)
-    const int bt = s.ldb >= OV_CHAIN_MAX_LDB ? 0 : ov_fused_bt(c);
+    // (dropout on the term layers' outputs lives in the per-level kernels only)
+    const int bt = (s.ldb >= OV_CHAIN_MAX_LDB || s.tdrop.rate > 0.f) ? 0 : ov_fused_bt(c);
     int rc;
     if (!refreshed && (rc = ov_sell_refresh(s, s.st))) return rc;      // also the gene layer's CSR-ordered copy, whatever the path
     if (bt == 0) {
@@ -3220,7 +3239,7 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne, bool term_part_only = fal
     const float* vals = c->P + c->lay.dec_vals;
     OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
 #define OV_DB(V) hipLaunchKernelGGL((ov_dec_bwd_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_row, c->csc_k, vals, s.ws.d, nb, ne, s.ldb, \
-                                    term_part_only ? c->csc_split : (const int32_t*)nullptr)
+                                    term_part_only ? c->csc_split : (const int32_t*)nullptr, s.tdrop, c->dims.C - c->dims.L)
     if (s.vec == 1) OV_DB(1); else if (s.vec == 2) OV_DB(2); else OV_DB(4);
 #undef OV_DB
     OV_LAUNCH_CHECK();
@@ -3235,7 +3254,7 @@ struct OvFinishArgs;
 static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fblocks = 0) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
-    const int bt = ov_fused_bt(c);
+    const int bt = s.tdrop.rate > 0.f ? 0 : ov_fused_bt(c);       // (term-layer dropout: per-level kernels only)
     int rc;
     if (bt == 0) {
         for (int lvl = d.K - 1; lvl >= 0; --lvl)
@@ -3357,6 +3376,7 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->want_xT = false;
     s->gw_part = nullptr; s->gw_bpart = nullptr; s->gw_rows = 0; s->gw_row0 = 0;
     s->gene_lds = false;
+    s->tdrop = OvTermDrop{0.f, 0, 0};
     return ONTOVAE_OK;
 }
 
@@ -3622,8 +3642,29 @@ extern "C" int ontovae_decoder_forward(const ontovae_ctx_t* ctx, const float* z,
 // (opt, ctx->M, ctx->V required); else the gradients of [dec_vals | dec_bias] go to ctx->Gr.  dz_out [B, L] (may be NULL):
 // dL/dz.  The general-purpose kernels (one wave per row for the weight gradient): this entry point is for models whose
 // ontology sits in the encoder (OntoEncVAE), not for the OntoVAE step, which has its own fused path.
-extern "C" int ontovae_decoder_backward(const ontovae_ctx_t* ctx, const float* drec, int32_t B, const ontovae_adamw_t* opt,
-                                        int32_t apply_update, float* dz_out, int64_t dz_ld, void* stream) {
+// ontovae_decoder_forward for a TRAINING pass of a model whose ontology sits in the encoder: Dropout(ctx->drop) on the output of
+// every term layer (OntoEncoder's blocks, modules.py:219-223, 231-233), keyed by rng_offset; the last layer (the heads) carries
+// none here (their Dropout(z_drop) belongs to ontovae_vae_decode_step).  With ctx->drop == 0 the same as ontovae_decoder_forward.
+extern "C" int ontovae_decoder_forward_train(const ontovae_ctx_t* ctx, const float* z, int32_t B, uint64_t rng_offset, float* rec_out,
+                                             int64_t rec_ld, void* stream) {
+    int rc = ov_check_ctx(ctx, B, false, true);
+    if (rc) return rc;
+    if (!z || !rec_out) { ontovae_set_error("decoder_forward_train: z or rec_out is NULL"); return ONTOVAE_EINVAL; }
+    const ontovae_dims_t& d = ctx->dims;
+    if (rec_ld < d.G) { ontovae_set_error("decoder_forward_train: output leading dimension too small"); return ONTOVAE_EINVAL; }
+    if (!(ctx->drop >= 0.f && ctx->drop < 1.f)) { ontovae_set_error("decoder_forward_train: drop = %g outside [0, 1)", (double)ctx->drop); return ONTOVAE_EINVAL; }
+    OvStep s;
+    ov_make_step(ctx, nullptr, nullptr, B, stream, &s);
+    s.tdrop = OvTermDrop{ctx->drop, ctx->seed, rng_offset};
+    dim3 grid((d.L + 31) / 32, (s.ldb + 31) / 32);
+    hipLaunchKernelGGL(ov_transpose_in_kernel, grid, dim3(256), 0, s.st, z, d.L, B, s.ldb, s.ws.act + (int64_t)(d.C - d.L) * s.ldb);
+    OV_LAUNCH_CHECK();
+    if ((rc = ov_dec_forward_terms(s))) return rc;
+    return ov_dec_gene<2>(s, rec_out, rec_ld);
+}
+
+extern "C" int ontovae_decoder_backward(const ontovae_ctx_t* ctx, const float* drec, int32_t B, uint64_t rng_offset,
+                                        const ontovae_adamw_t* opt, int32_t apply_update, float* dz_out, int64_t dz_ld, void* stream) {
     int rc = ov_check_ctx(ctx, B, apply_update != 0, true);
     if (rc) return rc;
     if (!drec) { ontovae_set_error("decoder_backward: drec is NULL"); return ONTOVAE_EINVAL; }
@@ -3634,6 +3675,7 @@ extern "C" int ontovae_decoder_backward(const ontovae_ctx_t* ctx, const float* d
     if (dz_out && dz_ld < d.L) { ontovae_set_error("decoder_backward: dz leading dimension too small"); return ONTOVAE_EINVAL; }
     OvStep s;
     ov_make_step(ctx, nullptr, nullptr, B, stream, &s);
+    s.tdrop = OvTermDrop{ctx->drop, ctx->seed, rng_offset};      // the masks of ontovae_decoder_forward_train with the same offset
     // dL/d(rec) into the gene rows of D, feature-major, zeros in the padded columns
     dim3 grid((d.G + 31) / 32, (s.ldb + 31) / 32);
     hipLaunchKernelGGL(ov_transpose_in_kernel, grid, dim3(256), 0, s.st, drec, d.G, B, s.ldb, s.ws.d + (int64_t)d.C * s.ldb);

@@ -15,8 +15,9 @@ layer the 2 Z head rows [mu; logvar]), and a step is three library calls:
     ontovae_decoder_forward  (masked encoder: genes -> heads [B, 2 Z])
     ontovae_vae_decode_step  (reparameterisation, dense Decoder, ELBO, backward to the heads, AdamW of the decoder)
     ontovae_decoder_backward (backward of the masked encoder, masked AdamW, clamp of its weights at zero)
-Dropout after the encoder's Linear layers (modules.py:222) is the identity in eval mode; in train mode a rate other than 0
-is refused (the operator's kernels have no dropout); the heads' Dropout(z_drop) and the Decoder's Dropout(drop) work.
+Dropout: after the encoder's Linear layers (modules.py:222) the per-level kernels of the operator multiply a layer's output by
+Philox keep-scales in training passes (ontovae_decoder_forward_train) and the finished gradient rows by the same scales in
+ontovae_decoder_backward; the heads' Dropout(z_drop) and the Decoder's Dropout(drop) are those of the plain VAE path.
 """
 import ctypes as C
 
@@ -113,7 +114,7 @@ class OntoEncoder(nn.Module):
         # the operator: every encoder block, then the two heads as ONE last layer of 2 Z rows [mu; logvar] over the same mask
         plan = MaskPlan(ms[:-1] + [np.vstack([ms[-1], ms[-1]])], 1)
         plan.layout = _operator_layout(plan)
-        object.__setattr__(self, "_engine", Engine(plan, self.device, 0.0, 0.0))
+        object.__setattr__(self, "_engine", Engine(plan, self.device, float(drop), 0.0))      # drop: Dropout behind every block
         e, Z = self._engine, self.latent_dim
         self.masks = _LazyMasks(e)                                      # (the last one shows the head mask twice)
         self.encoder = nn.ModuleList([nn.Sequential(PackedLinear(e, i), nn.Dropout(p=drop)) for i in range(plan.K - 1)])
@@ -144,10 +145,11 @@ class OntoEncoder(nn.Module):
         return h
 
     def forward(self, x):
-        """modules.py:226-238 in eval mode (the Dropout modules of a training pass live in OntoEncVAE's fused step)."""
-        if self.training and (self.drop or self.z_drop):
-            raise NotImplementedError("OntoEncoder.forward in train mode with dropout runs inside OntoEncVAE.forward / train_round")
-        h = self.heads(x)
+        """modules.py:226-238.  In train mode the blocks' Dropout is applied (Philox masks); the heads' Dropout(z_drop) is part
+        of what follows the encoder in OntoEncVAE's passes and refused here."""
+        if self.training and self.z_drop:
+            raise NotImplementedError("OntoEncoder.forward in train mode with z_drop > 0 runs inside OntoEncVAE.forward / train_round")
+        h = self.heads(x, train=self.training)
         Z = self.latent_dim
         return h[:, :Z].contiguous(), h[:, Z:].contiguous()
 
@@ -301,21 +303,14 @@ class OntoEncVAE(nn.Module):
         eps = torch.randn_like(sigma) if eps is None else torch.as_tensor(eps, dtype=sigma.dtype, device=sigma.device)
         return mu + eps * sigma
 
-    def _check_train_dropout(self):
-        if self.training and self.drop:
-            raise NotImplementedError("Dropout after the masked encoder layers (modules.py:222) is not implemented for training passes: "
-                                      "construct OntoEncVAE with drop=0 (z_drop is supported)")
-
     def get_embedding(self, x):
         """vae_model.py:540-551."""
-        self._check_train_dropout()
-        h = self.encoder.heads(x, train=False)
+        h = self.encoder.heads(x, train=self.training)
         return self._dense.decode_forward(h, eps=self._eps(h.shape[0]), train=self.training, want=("z",))["z"]
 
     def forward(self, x):
         """vae_model.py:553-563.  Returns (reconstruction, mu, log_var), each [B, .] on the device."""
-        self._check_train_dropout()
-        h = self.encoder.heads(x, train=False)
+        h = self.encoder.heads(x, train=self.training)
         o = self._dense.decode_forward(h, eps=self._eps(h.shape[0]), train=self.training)
         return o["recon"], o["mu"], o["log_var"]
 
@@ -345,7 +340,6 @@ class OntoEncVAE(nn.Module):
     def train_round(self, dataloader, lr, kl_coeff, optimizer, run=None):
         """vae_model.py:576-629: one epoch of forward, ELBO, backward, masked AdamW, clamp of the encoder weights."""
         self.train()
-        self._check_train_dropout()
         opt = _as_encvae_opt(self, optimizer, lr)
         dev = self.encoder._engine.device
         losses = torch.zeros(max(len(dataloader), 1), 3, dtype=torch.float32, device=dev)

@@ -474,12 +474,20 @@ class Engine:
 
     @_on_device
     def decoder_forward(self, z, act_out=None, rec_out=None, train=False):
-        """train: the pass is followed by decoder_backward on the same batch (sizes the training buffers of the workspace)."""
+        """train: a training pass of a model whose ontology sits in the encoder (ontovae_decoder_forward_train: Dropout(self.drop)
+        on the term layers' outputs); decoder_backward on the same batch follows and reuses the pass's Philox offset."""
         z = torch.as_tensor(z, dtype=torch.float32, device=self.device).contiguous()
         if z.dim() != 2 or z.shape[1] != self.plan.L:
             raise ValueError(f"expected z of shape [B, {self.plan.L}]")
         B = z.shape[0]
         ctx = self.ctx(B, train=train)
+        if train:
+            if rec_out is None or act_out is not None:
+                raise ValueError("a training pass of the operator returns rec_out only")
+            self._train_offset = self.next_offset()
+            _lib.check(_lib.lib().ontovae_decoder_forward_train(C.byref(ctx), _ptr(z), B, self._train_offset, _ptr(rec_out),
+                                                                rec_out.stride(0), self.stream()), "decoder_forward_train")
+            return
         _lib.check(_lib.lib().ontovae_decoder_forward(C.byref(ctx), _ptr(z), B, _ptr(act_out),
                                                       act_out.stride(0) if act_out is not None else 0, _ptr(rec_out),
                                                       rec_out.stride(0) if rec_out is not None else 0, self.stream()),
@@ -498,6 +506,6 @@ class Engine:
         else:
             self.ensure_grad_buffer()
         ctx = self.ctx(B, train=True)
-        _lib.check(_lib.lib().ontovae_decoder_backward(C.byref(ctx), _ptr(drec), B, C.byref(adam) if adam is not None else None,
-                                                       1 if apply_update else 0, _ptr(dz_out),
+        _lib.check(_lib.lib().ontovae_decoder_backward(C.byref(ctx), _ptr(drec), B, int(getattr(self, "_train_offset", 0)),
+                                                       C.byref(adam) if adam is not None else None, 1 if apply_update else 0, _ptr(dz_out),
                                                        dz_out.stride(0) if dz_out is not None else 0, self.stream()), "decoder_backward")

@@ -10,8 +10,8 @@ Reference map:
   masks                modules.py:211-216   weights multiplied by the masks at construction (no clamp there)
   train_round body     vae_model.py:598-625 ELBO, backward, gradient masks (:611-616), AdamW (:619), clamp(0) of the encoder weights (:622-625)
   val_round body       vae_model.py:651-655
-eps supplied.  Dropout after the encoder blocks: not modelled (rate 0); `scales` carries the keep-scales of the heads ("mu",
-"logvar") and of the decoder blocks as in oracle/vae_oracle.py.
+eps supplied.  Dropout: off unless the caller hands in keep-scales (`scales`: {"encoder.encoder.i": [B, width_i], "mu" /
+"logvar": [B, Z], "decoder.decoder.i": [B, width]}, entries 0 or 1 / (1 - p)), e.g. those of the HIP path's Philox streams.
 """
 import numpy as np
 
@@ -36,8 +36,10 @@ class OracleOntoEncVAE(OracleVAE):
         return names + super().param_names()
 
     # ------------------------------------------------------------------ forward
-    def encoder_forward(self, x):
-        """mu, logvar (before the heads' Dropout), the concatenation the heads see, and the inputs of every block."""
+    def encoder_forward(self, x, scales=None):
+        """mu, logvar (before the heads' Dropout), the concatenation the heads see, the inputs of every block and the blocks'
+        Linear outputs (what the reference's forward hooks see, vae_model.py:757-766).  scales: keep-scales of the blocks'
+        Dropout (modules.py:222), {"encoder.encoder.i": [B, width]}, train mode only."""
         p, dt = self.p, self.dt
         out = np.asarray(x, dtype=dt)
         ins, acts = [], []
@@ -45,6 +47,8 @@ class OracleOntoEncVAE(OracleVAE):
             ins.append(out)
             c = out @ p[f"encoder.encoder.{i}.0.weight"].T + p[f"encoder.encoder.{i}.0.bias"]
             acts.append(c)
+            if scales is not None and f"encoder.encoder.{i}" in scales:
+                c = c * np.asarray(scales[f"encoder.encoder.{i}"], dtype=dt)
             out = np.concatenate([c, out], axis=1)
         mu = out @ p["encoder.mu.0.weight"].T + p["encoder.mu.0.bias"]
         lv = out @ p["encoder.logvar.0.weight"].T + p["encoder.logvar.0.bias"]
@@ -54,7 +58,7 @@ class OracleOntoEncVAE(OracleVAE):
         p, dt = self.p, self.dt
         cache = [] if cache is None else cache
         sc = (lambda k: None) if scales is None else (lambda k: np.asarray(scales[k], dtype=dt))
-        mu, lv, top, ins, acts = self.encoder_forward(x)
+        mu, lv, top, ins, acts = self.encoder_forward(x, scales if train else None)
         if scales is not None:
             mu, lv = mu * sc("mu"), lv * sc("logvar")
         z = (mu + np.asarray(eps, dtype=dt) * np.exp(dt(0.5) * lv)).astype(dt)
@@ -105,6 +109,8 @@ class OracleOntoEncVAE(OracleVAE):
             W = p[f"encoder.encoder.{i}.0.weight"]
             no = W.shape[0]
             d_c, d_prev = d_out[:, :no], d_out[:, no:]
+            if scales is not None and f"encoder.encoder.{i}" in scales:
+                d_c = d_c * np.asarray(scales[f"encoder.encoder.{i}"], dtype=dt)
             g[f"encoder.encoder.{i}.0.weight"] = (d_c.T @ f["ins"][i]) * self.masks[i]      # vae_model.py:611-612
             g[f"encoder.encoder.{i}.0.bias"] = d_c.sum(axis=0, dtype=dt)
             d_out = d_prev + d_c @ W

@@ -134,9 +134,9 @@ def m_rec_cols(m, onto, fx, cols):
 
 
 def test_encvae_step_vs_oracle_with_dropout_on_heads_and_decoder():
-    """A larger random model (2 000 genes, 4 levels, 300 rows; the gene-wide first mask puts the panel beyond one LDS tile)
-    with z_drop = 0.5 on the heads and drop = 0 (see OntoEncVAE): loss and every gradient against the oracle fed with the
-    keep-scales of the HIP path's Philox stream, then three fused steps against the oracle's."""
+    """A larger random model (2 000 genes, 4 levels, 300 rows) with the reference's default rates, drop = 0.2 behind every
+    masked encoder block and in the Decoder, z_drop = 0.5 on the heads: loss and every gradient against the oracle fed with the
+    keep-scales of the HIP path's Philox streams; then three fused steps with dropout off against the oracle's."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import philox_oracle as ph
@@ -184,15 +184,22 @@ def test_encvae_step_vs_oracle_with_dropout_on_heads_and_decoder():
     o.load_state_dict(sd)
     x = np.log1p(rng.poisson(0.8, size=(B, G))).astype(np.float32)
     eps = rng.standard_normal((B, Z)).astype(np.float32)
-    z_drop, kc, lr = 0.5, 1e-3, 1e-3
-    m, _ = build(masks, sd, 0.0, z_drop)
+    drop, z_drop, kc, lr = 0.2, 0.5, 1e-3, 1e-3
+    m, _ = build(masks, sd, drop, z_drop)
     m.train()
-    d = m._dense
+    d, e = m._dense, m.encoder._engine
     off_ = d.rng_offset + 1
     scales = {"mu": ph.dropout_scale(z_drop, d.seed, off_, ph.STREAM_ZDROP_MU, Z, B),
-              "logvar": ph.dropout_scale(z_drop, d.seed, off_, ph.STREAM_ZDROP_LV, Z, B), "decoder.decoder.0": None}
-    scales = {k: (np.ones((B, Z), np.float32) if v is None else v) for k, v in scales.items()}
-    assert 0.35 < (scales["mu"] == 0).mean() < 0.65
+              "logvar": ph.dropout_scale(z_drop, d.seed, off_, ph.STREAM_ZDROP_LV, Z, B),
+              # the Decoder's block is block 1 of the dense engine (behind its one-unit dummy encoder block)
+              "decoder.decoder.0": ph.dropout_scale(drop, d.seed, off_ ^ (2 << 48), ph.STREAM_DROP, Z, B)}
+    # the masked encoder's blocks: one Philox stream over the operator's term nodes, keyed by (node, batch column)
+    nterm = e.plan.C - e.plan.L
+    full = ph.dropout_scale(drop, e.seed, e.rng_offset + 1, ph.STREAM_DROP, nterm, B)
+    for i in range(e.plan.K - 1):
+        n0, no = e.plan.layer_nodes[i]
+        scales[f"encoder.encoder.{i}"] = full[:, n0:n0 + no]
+    assert 0.35 < (scales["mu"] == 0).mean() < 0.65 and 0.1 < (full == 0).mean() < 0.3
     want = o.gradients(x, eps, kc, scales)
     out = torch.zeros(3, device="cuda")
     m.train_step(torch.as_tensor(x), None, kc, None, out, eps=torch.as_tensor(eps), apply_update=False)
@@ -243,9 +250,13 @@ def test_encvae_train_model_protocol_and_refusals(tmp_path, capsys):
         OntoEncVAE(onto, "d", neuronnum=3)
     with pytest.raises(ValueError):
         OntoEncVAE(onto, "nope")
-    m3 = OntoEncVAE(onto, "d", neuronnum=1, drop=0.2, z_drop=0.5)
-    m3.train()
-    with pytest.raises(NotImplementedError):
-        m3.train_round([(torch.as_tensor(X[:32]),)], 1e-3, 1e-4, None)
-    m3.eval()                                                          # eval mode: every Dropout is the identity
-    assert m3(torch.as_tensor(X[:8]))[0].shape == (8, G)
+    # the reference's default rates: a round trains, and eval mode ignores every Dropout
+    m3, _ = build(masks, sub(fx, "sd0/"), 0.2, 0.5, X=X)
+    assert np.isfinite(m3.train_round([(torch.as_tensor(X[:64]),)], 1e-3, 1e-4, None))
+    m4, _ = build(masks, sub(fx, "sd0/"), 0.2, 0.5, X=X)
+    m5, _ = build(masks, sub(fx, "sd0/"), X=X)
+    m4.eval(); m5.eval()
+    eps = torch.zeros(8, m4.latent_dim)
+    feed(m4, eps); feed(m5, eps)
+    for u, v in zip(m4(torch.as_tensor(X[:8])), m5(torch.as_tensor(X[:8]))):
+        assert torch.equal(u, v)
