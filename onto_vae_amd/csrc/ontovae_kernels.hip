@@ -1438,16 +1438,18 @@ __device__ __forceinline__ void ov_gather_cb(f32x4& acc, int k0, int k1, const i
 template <bool INDIRECT, int U>
 __device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const int32_t* __restrict__ rowidx,
                                               const int32_t* __restrict__ kidx, const float* __restrict__ vals,
-                                              const float* __restrict__ srccol, int ldb, int lane) {
+                                              const float* __restrict__ srccol, int ldb, int lane, const int r_empty = 0) {
+    // r_empty: a row of src that is always readable and finite, gathered with weight 0 by a group whose list is empty
+    // (forward: panel row 0; backward: the first gene row of D -- the panel rows of D are what the kernel is writing)
     const int s = lane & 7;
     int maxlen = len;                    // wave maximum of len
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
     maxlen = __builtin_amdgcn_readfirstlane(maxlen);
     auto fetch = [&](int e, int& r, float& w) {
-        // entry e of this group's list; beyond the list: the last row (or row 0 of an empty list), weight 0
+        // entry e of this group's list; beyond the list: the last row (or r_empty for an empty list), weight 0
         const int ee = max(min(e, len - 1), 0);
-        r = len > 0 ? rowidx[k0 + ee] : 0;
+        r = len > 0 ? rowidx[k0 + ee] : r_empty;
         w = 0.f;
         if (e < len) w = INDIRECT ? vals[kidx[k0 + e]] : vals[k0 + e];
     };
@@ -1503,7 +1505,7 @@ __device__ __forceinline__ void ov_gather_grp(f32x4& acc, int k0, int len, const
 __device__ __forceinline__ void ov_gather_grp_wgrad(f32x4& acc, int k0, int len, const int32_t* __restrict__ rowidx,
                                                     const int32_t* __restrict__ kidx, const float* __restrict__ vals,
                                                     const float* __restrict__ srccol, int ldb, int lane, const f32x4 aseg,
-                                                    float* __restrict__ part, const int kb_known = -1) {
+                                                    float* __restrict__ part, const int kb_known, const int r_empty) {
     const int s = lane & 7;
     int maxlen = len;                    // wave maximum of len
 #pragma unroll
@@ -1514,7 +1516,7 @@ __device__ __forceinline__ void ov_gather_grp_wgrad(f32x4& acc, int k0, int len,
     const int kb = kb_known >= 0 ? kb_known : (len > 0 ? kidx[k0] : 0);
     auto fetch = [&](int e, int& r, float& w, int& k) {
         const int ee = max(min(e, len - 1), 0);
-        r = len > 0 ? rowidx[k0 + ee] : 0;
+        r = len > 0 ? rowidx[k0 + ee] : r_empty;
         w = 0.f;
         k = -1;
         if (e < len) {
@@ -1814,9 +1816,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (wpart) {
         const f32x4 aseg = *reinterpret_cast<const f32x4*>(act + (int64_t)min(node, C - 1) * ldb + col0 + s4);
-        ov_gather_grp_wgrad(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz, kb);
+        ov_gather_grp_wgrad(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz, kb, C);
     } else {
-        ov_gather_grp<true, OV_GENE_BWD_U>(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane);
+        ov_gather_grp<true, OV_GENE_BWD_U>(acc, k0, len, csc_row, csc_k, vals, d + col0 + s4, ldb, lane, C);
     }
     if (node < C) {
         // dblk: column-group-major [ldb / 4][C][4], what a workgroup of the backward chain loads in one piece
@@ -1834,7 +1836,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 template <int NU>
 __device__ __forceinline__ void ov_gather_term_wgrad(f32x4 (&acc)[NU], int k0, int len, const int32_t* __restrict__ rowidx,
                                                      const float* __restrict__ vals, const float* __restrict__ srccol, int ldb, int lane,
-                                                     const f32x4 (&aseg)[NU], float* __restrict__ part, int kb) {
+                                                     const f32x4 (&aseg)[NU], float* __restrict__ part, int kb, const int r_empty) {
     const int s = lane & 7;
     int maxlen = len;                    // wave maximum of len
 #pragma unroll
@@ -1842,7 +1844,7 @@ __device__ __forceinline__ void ov_gather_term_wgrad(f32x4 (&acc)[NU], int k0, i
     maxlen = __builtin_amdgcn_readfirstlane(maxlen);
     auto fetch = [&](int e, int& r, float (&w)[NU], int& k) {
         const int ee = max(min(e, len - 1), 0);
-        r = len > 0 ? rowidx[k0 + ee] : 0;
+        r = len > 0 ? rowidx[k0 + ee] : r_empty;
         k = -1;
 #pragma unroll
         for (int j = 0; j < NU; ++j) w[j] = 0.f;
@@ -1910,7 +1912,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         aseg[j] = *reinterpret_cast<const f32x4*>(act + (int64_t)(n0 + j) * ldb + col0 + s4);
     }
-    ov_gather_term_wgrad<NU>(acc, k0, len, csc_row, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz, kb);
+    ov_gather_term_wgrad<NU>(acc, k0, len, csc_row, vals, d + col0 + s4, ldb, lane, aseg, wpart + (int64_t)map.cb * nnz, kb, C);
     if (node < C) {
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -1985,8 +1987,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int e = b0 + i;
-                en[i] = mine_ent[max(min(e, len - 1), 0)];          // an empty list reads record 0 of the tile's area (or stale LDS): weight forced to 0, row clamped
-                if (len <= 0) en[i].row = 0;
+                en[i] = mine_ent[max(min(e, len - 1), 0)];          // an empty list reads record 0 of the tile's area (or stale LDS): weight forced to 0,
+                if (len <= 0) en[i].row = C;                        // row = the first gene row of D (finite; the panel rows are being written here)
                 if (e >= len) {
 #pragma unroll
                     for (int j = 0; j < NU; ++j) en[i].w[j] = 0.f;

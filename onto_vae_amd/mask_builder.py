@@ -1,4 +1,4 @@
-"""Decoder masks straight from the trimmed ontology graph, without the dense intermediates.
+"""Decoder (and encoder) masks straight from the trimmed ontology graph, without the dense intermediates.
 
 The reference builds its masks in Ontobj.create_masks (onto_vae/ontobj.py:327-392) with
 utils.create_binary_matrix (onto_vae/utils.py:67-90): for every pair of depth levels it enumerates ALL
@@ -11,8 +11,11 @@ Orderings reproduced from the reference, because they define what a mask row / c
   * levels are the sorted distinct depths of annot['depth'], genes form one more level (max depth + 1)
     (ontobj.py:366-369);
   * inside a level the IDs are in sorted order (DataFrame.pivot sorts its index and columns, utils.py:86);
-  * mask i has the IDs of level i+1 as rows and [level i | level i-1 | ... | level 0] as columns
-    (ontobj.py:380-385).
+  * decoder mask i has the IDs of level i+1 as rows and [level i | level i-1 | ... | level 0] as columns
+    (ontobj.py:382-392);
+  * encoder mask i (OntoEncVAE) runs the other way: with K the gene level, its rows are the IDs of level K-1-i (the PARENTS)
+    and its columns the children [level K-i | level K-i+1 | ... | level K = genes] (ontobj.py:394-404: the transposed
+    pair matrices in the order itertools.combinations lists them).
 """
 import numpy as np
 
@@ -94,9 +97,36 @@ def links_from_graph(onto_dict, annot, genes):
     return (np.asarray(layer, dtype=np.int32), np.asarray(row, dtype=np.int32), np.asarray(col, dtype=np.int32)), shapes
 
 
+def encoder_links_from_graph(onto_dict, annot, genes):
+    """The encoder masks of Ontobj.create_masks(module='encoder') (ontobj.py:394-404) as links: arguments and return value
+    as links_from_graph."""
+    (dl, dr, dc), dshapes = links_from_graph(onto_dict, annot, genes)
+    K = len(dshapes)
+    sizes = [dshapes[0][1]] + [s[0] for s in dshapes]            # level sizes, level 0 (roots) .. level K (genes)
+    # a decoder link (layer i, row r, col c): child = (level i+1, r); c walks [level i | level i-1 | ... | level 0]
+    bounds = [np.cumsum([0] + [sizes[j] for j in range(i, -1, -1)]) for i in range(K)]
+    layer = np.empty(len(dl), np.int32)
+    row = np.empty(len(dl), np.int32)
+    col = np.empty(len(dl), np.int32)
+    for i in range(K):
+        sel = np.nonzero(dl == i)[0]
+        blk = np.searchsorted(bounds[i], dc[sel], side="right") - 1      # block j of mask i holds level i - j
+        plevel = i - blk
+        ppos = dc[sel] - bounds[i][blk]
+        layer[sel] = K - 1 - plevel
+        row[sel] = ppos
+        # columns of the parent's mask: [level p+1 | ... | level K]; the child sits at level i+1
+        starts = np.array([int(sum(sizes[p + 1:i + 1])) for p in range(i + 1)], np.int64)
+        col[sel] = starts[plevel] + dr[sel]
+    shapes = [(sizes[K - 1 - j], int(sum(sizes[K - j:]))) for j in range(K)]
+    order = np.lexsort((col, row, layer))
+    return (layer[order], row[order], col[order]), shapes
+
+
 def create_masks(ontobj, top_thresh=1000, bottom_thresh=30, module='decoder'):
-    """Drop-in for Ontobj.create_masks (ontobj.py:327-374), decoder module only: fills
-    ontobj.masks[key]['decoder'] with a PackedMasks built from ontobj.graph / .annot / .genes."""
+    """Drop-in for Ontobj.create_masks (ontobj.py:327-379): fills ontobj.masks[key][module] with a PackedMasks built from
+    ontobj.graph / .annot / .genes (module 'decoder' for OntoVAE, anything else the encoder masks of OntoEncVAE, as the
+    reference's else branch, ontobj.py:373-376)."""
     key = str(top_thresh) + '_' + str(bottom_thresh)
     if key not in ontobj.graph.keys():
         raise ValueError('Trimmed graph with specified thresholds missing, trim_dag function needs to be run first!')
@@ -104,9 +134,8 @@ def create_masks(ontobj, top_thresh=1000, bottom_thresh=30, module='decoder'):
         raise ValueError('Trimmed annotation with specified thresholds missing, trim_dag function needs to be run first!')
     if key not in ontobj.genes.keys():
         raise ValueError('Trimmed gene list with specified thresholds missing, trim_dag function needs to be run first!')
-    if module != 'decoder':
-        raise NotImplementedError("only the decoder masks are on the OntoVAE path (OntoEncVAE is out of scope)")
-    links, shapes = links_from_graph(ontobj.graph[key], ontobj.annot[key], ontobj.genes[key])
+    build = links_from_graph if module == 'decoder' else encoder_links_from_graph
+    links, shapes = build(ontobj.graph[key], ontobj.annot[key], ontobj.genes[key])
     if key not in ontobj.masks.keys():
         ontobj.masks[key] = {}
     ontobj.masks[key][module] = PackedMasks(links, shapes)

@@ -78,3 +78,23 @@ def close_vs_float64(got, ref32, ref64, factor=2.0, tau_frac=1e-3, rel=1e-4):
     if e_ref <= rel:
         ok = ok and e_got <= rel
     return ok, e_got, e_ref
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_device_pool(request):
+    """Before every GPU test: fill torch's caching-allocator pool with NaN and hand it back, so that the workspaces of the
+    test (torch.empty: whatever the pool holds) start as NaN instead of the zeros of fresh device memory.  A kernel that reads
+    a workspace cell nothing wrote -- a padded column, a fallback row of an empty list gathered with weight 0 -- then
+    shows up as NaN in the result instead of passing by luck (found that way: the backward gene kernels' empty lists used
+    to gather panel row 0 of D, which the same launch writes)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        nan = float("nan")
+        big = [torch.full((1 << 26,), nan, device="cuda") for _ in range(8)]                      # 8 x 256 MB
+        small = [torch.full((n,), nan, device="cuda") for n in (1 << 8, 1 << 11, 1 << 14, 1 << 17, 1 << 20, 1 << 23) for _ in range(6)]
+        torch.cuda.synchronize()
+        del big, small
+    yield
