@@ -594,6 +594,140 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// The encoder-forward form of ov_gemm_lds_kernel (WM = 1, WN = 4, both operands K-contiguous) for large batches, where the
+// K loop is long and the matrix pipe sets the pace: two LDS stages and ONE barrier per K-step instead of two, the MFMA
+// fragments of the next group of 8 k read from LDS while the current group's 12 MFMAs run (two register sets), global loads
+// two stages ahead (a whole step to land), and the next stage written to the other LDS buffer under the step's first MFMAs, so
+// that at the barrier a wave has nothing left to wait for but the other waves.  Same tiles, same operand order and same summation order as ov_gemm_lds_kernel: bit-identical
+// results.
+// -------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void ov_gemm_lds2_kernel(const OvGemm p) {
+    constexpr int MT = 3, BK = 32, LDK = BK + 4;
+    constexpr int RA = 32 * MT, RB = 128;
+    constexpr int UA = RA * 8 / 256, UB = RB * 8 / 256;
+    constexpr int STAGE = (RA + RB) * LDK;        // floats per LDS stage
+    extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
+    const int tid = threadIdx.x;
+    const int lane = ov_lane();
+    const int wave = ov_wave_id();
+    const int i = lane & 31, h = lane >> 5;
+    int by = blockIdx.y, bz = blockIdx.z;
+    if (gridDim.x == 1 && gridDim.z % 8 == 0) {          // (as ov_gemm_lds_kernel: row tiles of one K slab on one XCD)
+        const int id = blockIdx.y + gridDim.y * blockIdx.z, ny = gridDim.y;
+        const int xcd = id & 7, j = id >> 3;
+        bz = xcd + 8 * (j / ny);
+        by = j % ny;
+    }
+    const int m0 = by * RA, n0 = blockIdx.x * RB;
+    const int kb0 = bz * p.kchunk;
+    const int kb1 = min(p.K, kb0 + p.kchunk);
+    const int kq4 = 4 * (tid & 7);
+    const float* asrc[UA];
+    const float* bsrc[UB];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) asrc[u] = p.A + (int64_t)min(m0 + (tid >> 3) + 32 * u, p.M - 1) * p.lda;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        const int n = min(n0 + (tid >> 3) + 32 * u, p.N - 1);
+        bsrc[u] = p.B + (p.bgather ? (int64_t)p.bgather[n] : (int64_t)n) * p.ldb;
+    }
+    const int dst0 = (tid >> 3) * LDK + kq4;      // + 32 u rows; B behind the RA rows of A
+    f32x4 ra[UA], rb[UB];
+    const int kclamp = (p.K - 1) & ~3;
+    auto gload = [&](int k0) {                    // every lane, every load; clamped into the row (see ov_gemm_lds_kernel)
+        const int k = min(k0 + kq4, kclamp);
+#pragma unroll
+        for (int u = 0; u < UA; ++u) ra[u] = *reinterpret_cast<const f32x4*>(asrc[u] + k);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) rb[u] = *reinterpret_cast<const f32x4*>(bsrc[u] + k);
+    };
+    // (a form without the K-tail selects -- walking pointers, plain LDS stores, 13 instead of ~50 vector-ALU instructions per
+    // step -- measured 1-3 % SLOWER on the same box at 8192 and 16384 columns: the selects ride in the MFMAs' shadow)
+    auto lstore = [&](int k0, float* st) {
+        const int k = k0 + kq4;
+        const bool o0 = k < kb1, o1 = k + 1 < kb1, o2 = k + 2 < kb1, o3 = k + 3 < kb1;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            f32x4 v;
+            v.x = o0 ? ra[u].x : 0.f; v.y = o1 ? ra[u].y : 0.f; v.z = o2 ? ra[u].z : 0.f; v.w = o3 ? ra[u].w : 0.f;
+            *reinterpret_cast<f32x4*>(st + dst0 + 32 * u * LDK) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            f32x4 v;
+            v.x = o0 ? rb[u].x : 0.f; v.y = o1 ? rb[u].y : 0.f; v.z = o2 ? rb[u].z : 0.f; v.w = o3 ? rb[u].w : 0.f;
+            *reinterpret_cast<f32x4*>(st + RA * LDK + dst0 + 32 * u * LDK) = v;
+        }
+    };
+    // fragments of 4 k: lane (i, h) holds k = 8 g + 4 h .. + 3 of group g
+    const int fa_off = i * LDK + 4 * h, fb_off = (RA + wave * 32 + i) * LDK + 4 * h;
+    auto fread = [&](const float* st, int g, f32x4 (&fa)[MT], f32x4& fb) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const f32x4*>(st + fa_off + 32 * mt * LDK + 8 * g);
+        fb = *reinterpret_cast<const f32x4*>(st + fb_off + 8 * g);
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    auto mfmas = [&](const f32x4 (&fa)[MT], const f32x4& fb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][t], fb[t], acc[mt], 0, 0, 0);
+    };
+
+    // LDS holds stage k (being multiplied) and stage k + 1 (written at the start of step k from registers whose loads were
+    // requested a whole step earlier); the registers then take the loads of stage k + 2.
+    gload(kb0);
+    lstore(kb0, ov_gemm_lds);
+    gload(kb0 + BK);
+    __syncthreads();
+    int cur = 0;
+    f32x4 fa0[MT], fb0, fa1[MT], fb1;
+    fread(ov_gemm_lds, 0, fa0, fb0);
+    for (int k0 = kb0; k0 < kb1; k0 += BK) {
+        const float* st = ov_gemm_lds + cur * STAGE;
+        float* nx = ov_gemm_lds + (cur ^ 1) * STAGE;
+        fread(st, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(k0 + BK, nx);                     // the other buffer: nobody reads it before the barrier below; the scheduler
+        gload(k0 + 2 * BK);                      // spreads these between the first group's MFMAs
+        mfmas(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        fread(st, 2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        fread(st, 3, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                         // next stage visible; this wave's reads of the current one have all returned
+        fread(nx, 0, fa0, fb0);                  // the next step's first fragments land under this step's last 12 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa1, fb1);
+        cur ^= 1;
+    }
+
+    const int n = n0 + wave * 32 + i;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int mb = m0 + 32 * mt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < p.M && n < p.N) {
+                if (EPI == OV_EPI_STORE) p.C[(int64_t)bz * p.slab_stride + (int64_t)m * p.ldc + n] = acc[mt][r];
+                else p.C[(int64_t)m * p.ldc + n] = acc[mt][r] + p.bias[m];
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // dW0 = dh x (+ AdamW) for batches of at most 128 rows: the weight-gradient of the first encoder layer
 // (gradient of modules.py:46, optimizer step of vae_model.py:172).
 //

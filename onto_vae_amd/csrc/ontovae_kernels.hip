@@ -2773,6 +2773,18 @@ static int ov_launch_gemm_lds(const OvGemm& g, int S, hipStream_t st) {
     return ONTOVAE_OK;
 }
 
+// the two-stage form of the encoder-forward product (ov_gemm_lds2_kernel)
+template <int EPI>
+static int ov_launch_gemm_lds2(const OvGemm& g, int S, hipStream_t st) {
+    dim3 grid((g.N + 127) / 128, (g.M + 95) / 96, S);
+    const size_t lds = (size_t)2 * (96 + 128) * 36 * sizeof(float);
+    auto kern = ov_gemm_lds2_kernel<EPI>;
+    { int rc_ = ov_allow_lds(reinterpret_cast<const void*>(kern), lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);
+    OV_LAUNCH_CHECK();
+    return ONTOVAE_OK;
+}
+
 static inline bool ov_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // dW0 with the x fragment resident in registers (K <= 128, dh rows 16-B aligned)
@@ -2923,6 +2935,8 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     g.dbg = OV_DBG((s.c->flags >> 18) & 3);
     OvProfScope prof(ONTOVAE_PHASE_ENC_GEMM, s.st);
     const int nt = ov_enc_nt(s.B);
+    // from 1024 columns on: two LDS stages, one barrier per K-step (8192 columns: 1058 -> 1015 us, 1024: 166 -> 162, same box)
+    if (vec && nt == 4 && s.ldb >= 1024 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds2<OV_EPI_STORE>(g, Seff, s.st);
     if (vec && nt == 4 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds<1, 4, true, OV_EPI_STORE>(g, Seff, s.st);
     if (nt == 1) return ov_launch_gemm<3, 1, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
     if (nt == 2) return ov_launch_gemm<3, 2, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
