@@ -165,4 +165,157 @@ __global__ __launch_bounds__(256) void ov_bf16_gemm_tn_kernel(const OvBfGemm p) 
         }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Second version of the product kernel (round 3): the same 128 x 128 tile, operand order and summation order as
+// ov_bf16_gemm_tn_kernel (bit-identical sums), built like ov_gemm_lds2_kernel: two LDS stages and ONE barrier per 64-deep
+// K-step, the fragments of the next 16 k read while the current 4 MFMAs run (two register sets), global loads two steps ahead,
+// the next step's first fragments read across the barrier.  EPI 0: fp32 tile to slab z.  EPI 1 (dW0): the tile is the
+// gradient of a tile of W0 -- AdamW (the arithmetic of ov_adamw_flat_kernel) on w / exp_avg / exp_avg_sq in the epilogue,
+// no gradient buffer, no second pass.
+// -------------------------------------------------------------------------------------------------
+struct OvBfGemm2 {
+    OvBfGemm g;
+    float* Pm; float* Pv;                // EPI 1: exp_avg, exp_avg_sq (g.C = the weights), same leading dimension g.ldc
+    OvAdam adam;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void ov_bf16_gemm2_kernel(const OvBfGemm2 q) {       // two workgroups per CU (LDS: 2 x 72 KB)
+    const OvBfGemm& p = q.g;
+    constexpr int ROWS = OV_BF_BM + OV_BF_BN, STAGE = ROWS * OV_BF_LD;      // bf16 elements per stage: A rows, then B rows
+    extern __shared__ __attribute__((aligned(16))) uint16_t ov_bf_lds[];
+    // workgroups are dealt to the 8 XCDs round-robin by linear id: the row tiles (y) of one column tile and slab read the same
+    // B rows, so they are renumbered to be neighbours in time on one XCD
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nx = gridDim.x, ny = gridDim.y;
+        const int id = blockIdx.x + nx * blockIdx.y;
+        if ((nx * ny) % 8 == 0) {
+            const int xcd = id & 7, j = id >> 3, per = nx * ny / 8;      // XCD xcd owns linear tiles [xcd * per, (xcd + 1) * per)
+            const int t = xcd * per + j;
+            by = t % ny; bx = t / ny;
+        }
+    }
+    const int n0 = bx * OV_BF_BN, m0 = by * OV_BF_BM, z = blockIdx.z;
+    const int kbeg = z * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lc8 = (tid & 7) * 8, lr = tid >> 3;                       // 16-B piece of the K step, row (+ 32 i)
+    const uint16_t* asrc[4];
+    const uint16_t* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asrc[i] = p.A + (int64_t)min(m0 + lr + 32 * i, p.M - 1) * p.lda;
+        bsrc[i] = p.B + (int64_t)min(n0 + lr + 32 * i, p.N - 1) * p.ldb;
+    }
+    const int kclamp = (p.K - 1) & ~7;                                   // the last 16-B piece of a row inside the K range
+    ov_u32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {               // every lane, every load, addresses clamped into the row (exact wait counts)
+        const int k = min(k0 + lc8, kclamp);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const ov_u32x4*>(asrc[i] + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const ov_u32x4*>(bsrc[i] + k);
+    };
+    const int dst0 = lr * OV_BF_LD + lc8;
+    auto lstore = [&](int k0, uint16_t* st) {    // K % 8 == 0: a piece is wholly inside or wholly outside the range
+        const bool ok = k0 + lc8 < kend;
+        const ov_u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<ov_u32x4*>(st + dst0 + 32 * i * OV_BF_LD) = ok ? ra[i] : zero;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<ov_u32x4*>(st + (OV_BF_BM + 32 * i) * OV_BF_LD + dst0) = ok ? rb[i] : zero;
+    };
+    const int fa_off = (wm + (lane & 31)) * OV_BF_LD + (lane >> 5) * 8;
+    const int fb_off = (OV_BF_BM + wn + (lane & 31)) * OV_BF_LD + (lane >> 5) * 8;
+    auto fread = [&](const uint16_t* st, int g, ov_bf16x8 (&a)[2], ov_bf16x8 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i] = *reinterpret_cast<const ov_bf16x8*>(st + fa_off + 32 * i * OV_BF_LD + 16 * g);
+            b[i] = *reinterpret_cast<const ov_bf16x8*>(st + fb_off + 32 * i * OV_BF_LD + 16 * g);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto mfmas = [&](const ov_bf16x8 (&a)[2], const ov_bf16x8 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+
+    if (kbeg < kend) {
+        gload(kbeg);
+        lstore(kbeg, ov_bf_lds);
+        gload(kbeg + OV_BF_BK);
+        __syncthreads();
+        int cur = 0;
+        ov_bf16x8 a0[2], b0[2], a1[2], b1[2];
+        fread(ov_bf_lds, 0, a0, b0);
+        for (int k0 = kbeg; k0 < kend; k0 += OV_BF_BK) {
+            const uint16_t* st = ov_bf_lds + cur * STAGE;
+            uint16_t* nx = ov_bf_lds + (cur ^ 1) * STAGE;
+            fread(st, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(k0 + OV_BF_BK, nx);               // the other buffer: nobody reads it before the barrier below
+            gload(k0 + 2 * OV_BF_BK);
+            mfmas(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            fread(st, 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            fread(st, 3, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                         // next stage visible; this wave's reads of the current one have returned
+            fread(nx, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a1, b1);
+            cur ^= 1;
+        }
+    }
+
+    // C/D map of a 32 x 32 tile: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + (lane & 31);
+            const int mb = m0 + wm + 32 * i + (lane >> 5) * 4;
+            if (EPI == 0) {
+                float* C = p.C + (int64_t)z * p.slab_stride;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e >> 2) * 8 + (e & 3);
+                    if (m < p.M && n < p.N) C[(int64_t)m * p.ldc + n] = acc[i][j][e];
+                }
+            } else {
+                float w[16], mm[16], vv[16];
+                bool ok[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e >> 2) * 8 + (e & 3);
+                    ok[e] = m < p.M && n < p.N;
+                    const int64_t idx = (int64_t)min(m, p.M - 1) * p.ldc + min(n, p.N - 1);
+                    w[e] = p.C[idx]; mm[e] = q.Pm[idx]; vv[e] = q.Pv[idx];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ov_adamw(w[e], mm[e], vv[e], acc[i][j][e], q.adam, false);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e >> 2) * 8 + (e & 3);
+                    const int64_t idx = (int64_t)m * p.ldc + n;
+                    if (ok[e]) { p.C[idx] = w[e]; q.Pm[idx] = mm[e]; q.Pv[idx] = vv[e]; }
+                }
+            }
+        }
+}
+
 #endif

@@ -2881,14 +2881,32 @@ static int ov_side_join(OvStep& s) {
 }
 static inline hipStream_t ov_side_stream(const OvStep& s) { return s.side ? s.side->st : s.st; }
 
-static int ov_bf16_gemm(const OvBfGemm& g, int S, hipStream_t st) {
+// adam != NULL: g.C holds the weights, Pm / Pv their moments, and the product is applied to them as a gradient (AdamW epilogue)
+// two_stage: ov_bf16_gemm2_kernel (two workgroups per CU, loads two K-steps ahead) instead of ov_bf16_gemm_tn_kernel (one LDS stage, up to
+// four workgroups per CU).  Measured at 8192 rows: the encoder-forward product (K = 20 000 genes, every workgroup streams x) 205 us with
+// the first, 255 with the second -- its short 64-deep steps are bound by load latency, which more workgroups per CU hide better than two
+// steps of prefetch; dW0 (K = batch) 205 + 33 us of AdamW pass with the first, 198 us with the second and its AdamW epilogue.
+static int ov_bf16_gemm(const OvBfGemm& g, int S, hipStream_t st, const OvAdam* adam = nullptr, float* Pm = nullptr, float* Pv = nullptr,
+                        bool two_stage = false) {
     if (g.M < 1 || g.N < 1 || g.K < 1) return ONTOVAE_OK;
     if ((g.K % 8) || (g.lda % 8) || (g.ldb % 8) || (g.kchunk % OV_BF_BK) || !ov_al16(g.A) || !ov_al16(g.B)) {
         ontovae_set_error("bf16 gemm: K = %d, lda = %lld, ldb = %lld, kchunk = %d or operand alignment not supported", g.K, (long long)g.lda,
                           (long long)g.ldb, g.kchunk);
         return ONTOVAE_EINVAL;
     }
-    hipLaunchKernelGGL(ov_bf16_gemm_tn_kernel, dim3((g.N + OV_BF_BN - 1) / OV_BF_BN, (g.M + OV_BF_BM - 1) / OV_BF_BM, S), dim3(256), 0, st, g);
+    const OvBfGemm2 q{g, Pm, Pv, adam ? *adam : OvAdam{}};
+    const size_t lds = (size_t)2 * (OV_BF_BM + OV_BF_BN) * OV_BF_LD * sizeof(uint16_t);
+    const dim3 grid((g.N + OV_BF_BN - 1) / OV_BF_BN, (g.M + OV_BF_BM - 1) / OV_BF_BM, S);
+    if (adam) {
+        if (S != 1 || !Pm || !Pv) { ontovae_set_error("bf16 gemm: the AdamW epilogue needs one K slab and the moment buffers"); return ONTOVAE_EINVAL; }
+        { int rc_ = ov_allow_lds(reinterpret_cast<const void*>(ov_bf16_gemm2_kernel<1>), lds); if (rc_) return rc_; }
+        hipLaunchKernelGGL(ov_bf16_gemm2_kernel<1>, grid, dim3(256), lds, st, q);
+    } else if (two_stage) {
+        { int rc_ = ov_allow_lds(reinterpret_cast<const void*>(ov_bf16_gemm2_kernel<0>), lds); if (rc_) return rc_; }
+        hipLaunchKernelGGL(ov_bf16_gemm2_kernel<0>, grid, dim3(256), lds, st, q);
+    } else {
+        hipLaunchKernelGGL(ov_bf16_gemm_tn_kernel, grid, dim3(256), 0, st, g);
+    }
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
@@ -2909,12 +2927,17 @@ static int ov_enc_gemm_bf16(OvStep& s, int* S_out) {
     OV_LAUNCH_CHECK();
     const int tiles = ((d.L + OV_BF_BM - 1) / OV_BF_BM) * ((s.B + OV_BF_BN - 1) / OV_BF_BN);
     int S = std::max(1, std::min(std::min((512 + tiles - 1) / tiles, 64), std::max(1, d.G / 512)));
+    // up to 4096 columns the two-stage kernel with about one workgroup per CU (two from 64 tiles on) is ahead of the one-stage
+    // kernel at its four per CU (1024 columns: 36.7 against 46.8 us, 2048: 70.6 / 80.8, 4096: 115 / ~135); at 8192 it is behind
+    // (242-257 against 228: see ov_bf16_gemm)
+    const bool two_stage = tiles <= 96;
+    if (two_stage) S = std::max(1, std::min((tiles < 64 ? 256 : 512) / tiles, std::max(1, d.G / 512)));
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, s.ws.slab_floats / ((int64_t)d.L * s.ldb)));
     const int kchunk = ((d.G + S - 1) / S + OV_BF_BK - 1) / OV_BF_BK * OV_BF_BK;
     const int Seff = (d.G + kchunk - 1) / kchunk;
     *S_out = Seff;
     const OvBfGemm g{bw.wb, d.G, bw.xb, d.G, s.ws.slab, s.ldb, (int64_t)d.L * s.ldb, d.L, s.B, d.G, kchunk};
-    return ov_bf16_gemm(g, Seff, s.st);
+    return ov_bf16_gemm(g, Seff, s.st, nullptr, nullptr, nullptr, two_stage);
 }
 
 // x W0^T -> split-K slabs  (modules.py:46)
@@ -3904,24 +3927,20 @@ static int ov_dw0(OvStep& s, const ontovae_adamw_t* opt, int apply, int l0 = 0, 
     if (l1 < 0) l1 = d.L;
     const int64_t roff = (int64_t)l0 * d.G;
     if (c->flags & ONTOVAE_FLAG_BF16_GEMM) {
-        // bf16 variant: dh rows -> dhb, dW0 rows = dhb . xT^T into the gradient buffer, then (fused-update callers) the flat AdamW
-        if (!c->Gr) { ontovae_set_error("dW0 (bf16 variant): the gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
+        // bf16 variant: dh rows -> dhb, dW0 rows = dhb . xT^T with AdamW in the product's epilogue (fused-update callers) or into
+        // the gradient buffer (data parallel: the exchange comes first)
+        if (!apply && !c->Gr) { ontovae_set_error("dW0 (bf16 variant): the gradient buffer Gr is NULL"); return ONTOVAE_EINVAL; }
         OvBfWs bw;
         ov_bf16_carve(d, c->max_batch, c->bf16_ws, &bw);
         OvProfScope prof(ONTOVAE_PHASE_DW0, s.st);
         hipLaunchKernelGGL(ov_bf16_convert_rows_kernel, dim3((s.ldb + 1023) / 1024, l1 - l0), dim3(256), 0, s.st,
                            s.ws.dh + (int64_t)l0 * s.ldb, (int64_t)s.ldb, s.B, bw.dhb + (int64_t)l0 * s.ldb, (int64_t)s.ldb);
         OV_LAUNCH_CHECK();
-        const OvBfGemm bg{bw.dhb + (int64_t)l0 * s.ldb, s.ldb, bw.xT, s.ldb, c->Gr + c->lay.W0 + roff, d.G, 0, l1 - l0, d.G, s.ldb,
-                          (s.ldb + OV_BF_BK - 1) / OV_BF_BK * OV_BF_BK};
-        int rcb = ov_bf16_gemm(bg, 1, s.st);
-        if (rcb || !apply) return rcb;
-        const int64_t n = (int64_t)(l1 - l0) * d.G;
-        hipLaunchKernelGGL(ov_adamw_flat_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s.st,
-                           c->P + c->lay.W0 + roff, c->M + c->lay.W0 + roff, c->V + c->lay.W0 + roff, c->Gr + c->lay.W0 + roff, n,
-                           (int64_t)-1, (int64_t)-1, ov_adam_from(opt));
-        OV_LAUNCH_CHECK();
-        return ONTOVAE_OK;
+        OvBfGemm bg{bw.dhb + (int64_t)l0 * s.ldb, s.ldb, bw.xT, s.ldb, apply ? c->P + c->lay.W0 + roff : c->Gr + c->lay.W0 + roff, d.G, 0,
+                    l1 - l0, d.G, s.ldb, (s.ldb + OV_BF_BK - 1) / OV_BF_BK * OV_BF_BK};
+        if (!apply) return ov_bf16_gemm(bg, 1, s.st, nullptr, nullptr, nullptr, true);
+        const OvAdam adam = ov_adam_from(opt);
+        return ov_bf16_gemm(bg, 1, s.st, &adam, c->M + c->lay.W0 + roff, c->V + c->lay.W0 + roff);
     }
     OvGemm g{};
     g.M = l1 - l0; g.N = d.G; g.K = s.B;
