@@ -400,8 +400,9 @@ __global__ __launch_bounds__(256) void ov_gemm_kernel(const OvGemm p) {
 //   dW0            : WM = 4, WN = 1, B n-contiguous (x[row(b), g]), K = batch, AdamW epilogue
 // Requires 16-B aligned rows (lda, ldb multiples of 4); the host falls back to ov_gemm_kernel otherwise.
 // -------------------------------------------------------------------------------------------------
+// (a device function, so that other work can share its launch: bid / gdim stand in for the block index and the grid size)
 template <int WM, int WN, bool B_KC, int EPI>
-__global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
+__device__ __forceinline__ void ov_gemm_lds_body(const OvGemm& p, const dim3 bid, const dim3 gdim) {
     constexpr int MT = 3, BK = 32, LDK = BK + 4;
     constexpr int RA = 32 * MT * WM;              // A rows per workgroup
     constexpr int RB = 32 * WN;                   // B columns (n) per workgroup
@@ -419,14 +420,14 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
     const int wm = WM == 4 ? wave : 0, wn = WN == 4 ? wave : 0;
     // Workgroups are dealt to the 8 XCDs round-robin by linear id.  The row tiles (y) of one K slab (z) read the same
     // B tile, so they are renumbered to share an XCD (and its L2): linear id = xcd + 8 j  ->  z = xcd + 8 (j / ny), y = j % ny.
-    int by = blockIdx.y, bz = blockIdx.z;
-    if (gridDim.x == 1 && gridDim.z % 8 == 0) {
-        const int id = blockIdx.y + gridDim.y * blockIdx.z, ny = gridDim.y;
+    int by = bid.y, bz = bid.z;
+    if (gdim.x == 1 && gdim.z % 8 == 0) {
+        const int id = bid.y + gdim.y * bid.z, ny = gdim.y;
         const int xcd = id & 7, j = id >> 3;
         bz = xcd + 8 * (j / ny);
         by = j % ny;
     }
-    const int m0 = by * RA, n0 = blockIdx.x * RB;
+    const int m0 = by * RA, n0 = bid.x * RB;
     const int kb0 = bz * p.kchunk;
     const int kb1 = min(p.K, kb0 + p.kchunk);
     if (!B_KC) {
@@ -591,6 +592,11 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
             }
         }
     }
+}
+
+template <int WM, int WN, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
+    ov_gemm_lds_body<WM, WN, B_KC, EPI>(p, blockIdx, gridDim);
 }
 
 // -------------------------------------------------------------------------------------------------

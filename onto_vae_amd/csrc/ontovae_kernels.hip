@@ -181,6 +181,7 @@ static inline int ov_ldb(int B) {
 // =================================================================================================
 // Workspace
 // =================================================================================================
+#define OV_DWH_SMAX 16
 struct OvWs {
     float *slab, *xhat, *a, *mulv, *epsw, *act, *d, *dblk, *dmulv, *da, *dh;
     float *bn_mean, *bn_invstd, *bn_bwd_local;
@@ -188,6 +189,7 @@ struct OvWs {
     float *wpart;              // [ldb / 32][nnz + C + G] weight-gradient partials of the 32-column blocks
     float *wgene;              // [nnz - nnz_term] gene-layer weights in CSR order, refreshed from P at the start of every pass
     float *whT;                // [L][2 L] transposed copy of the head weights (da at large batches)
+    float *whslab;             // [OV_DWH_SMAX][2 L][L] split-K slabs of dWh at large batches
     float *gb4;                // [ldb / 4][lanes of the gene layer's SELL form] gene bias gradient partials of ov_gene_lds_kernel
     int64_t slab_floats;
     int npart_max;
@@ -253,6 +255,7 @@ static int64_t ov_carve(const ontovae_dims_t& d, int max_batch, int train_batch,
     w.wgene = take((int64_t)d.nnz - d.nnz_term);
     w.gb4 = take((tldb / 4) * ov_gsell_lanes_max(d.G));
     w.whT = take(2 * L * L);
+    w.whslab = take((int64_t)OV_DWH_SMAX * 2 * L * L);
     w.slab_floats = slab;
     w.npart_max = (int)npart;
     if (ws) *ws = w;
@@ -2355,6 +2358,39 @@ __global__ __launch_bounds__(256) void ov_dwh_bn_kernel(const OvGemm g, int gx, 
     ov_bn_bwd_body(bn, b - gx * gy);
 }
 
+// The same launch from 2048 columns on: dWh as LDS-staged 96 x 128 tiles over split-K slabs of the batch (the 32 x 32 tiles above
+// load MFMA fragments straight from global memory, 32 lines per wave instruction: 169 us at 8192 columns for 4.2 GFLOP), the
+// BatchNorm backward beside it; ov_wh_combine_kernel then adds the slabs in slab order and applies AdamW.
+__global__ __launch_bounds__(256) void ov_dwh_lds_bn_kernel(const OvGemm g, int gx, int gy, int gz, const OvBnBwdArgs bn) {
+    const int b = blockIdx.x;
+    const int ngemm = gx * gy * gz;
+    if (b < ngemm) {
+        ov_gemm_lds_body<1, 4, true, OV_EPI_STORE>(g, dim3(b % gx, (b / gx) % gy, b / (gx * gy)), dim3(gx, gy, gz));
+        return;
+    }
+    ov_bn_bwd_body(bn, b - ngemm);
+}
+__global__ __launch_bounds__(256) void ov_wh_combine_kernel(const float* __restrict__ slabs, int S, int64_t n, float* __restrict__ P,
+                                                           float* __restrict__ M, float* __restrict__ V, float* __restrict__ Gr,
+                                                           int apply, OvAdam adam) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;                                        // n % 4 == 0 (host check)
+    f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + i);
+    for (int z = 1; z < S; ++z) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (int64_t)z * n + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (!apply) { *reinterpret_cast<f32x4*>(Gr + i) = acc; return; }
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(P + i), m4 = *reinterpret_cast<const f32x4*>(M + i), v4 = *reinterpret_cast<const f32x4*>(V + i);
+    float w[4] = {w4.x, w4.y, w4.z, w4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+    const float g[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov_adamw(w[e], m[e], v[e], g[e], adam, false);
+    *reinterpret_cast<f32x4*>(P + i) = f32x4{w[0], w[1], w[2], w[3]};
+    *reinterpret_cast<f32x4*>(M + i) = f32x4{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<f32x4*>(V + i) = f32x4{v[0], v[1], v[2], v[3]};
+}
+
 // Weight gradient at mask positions only (SDDMM) + fused AdamW + clamp(0), one wave per row node:
 //   g_k = sum_b D[n, b] * ACT[colidx[k], b];   gb = sum_b D[n, b]
 // The padded batch columns of D are zero by construction, so no masking is needed in the dots.
@@ -3891,7 +3927,25 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     const int bn_blocks = d.L;
     if (!s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS)) {
         ov_prof_pair_begin(s.st);
-        {
+        const int64_t nwh = (int64_t)2 * d.L * d.L;
+        // (from 2048 columns: 49 -> 43 us there, 169 -> 101 at 8192; at 1024 the combine launch costs what the tiles gain)
+        if (s.ldb >= 2048 && (d.L % 4 == 0) && ov_al16(gw.A) && ov_al16(gw.B) && ov_al16(gw.C) && (!apply || (ov_al16(gw.Pm) && ov_al16(gw.Pv)))) {
+            OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
+            // 96 x 128 tiles of [2L, L], the batch in split-K slabs: about one workgroup per CU beside the L BatchNorm workgroups
+            const int gx = (d.L + 127) / 128, gy = (2 * d.L + 95) / 96;
+            const int S = std::max(1, std::min(std::min(OV_DWH_SMAX, 256 / std::max(gx * gy, 1)), s.ldb / 64));
+            OvGemm gl = gw;
+            gl.kchunk = ((s.B + S - 1) / S + 31) / 32 * 32;
+            const int gz = (s.B + gl.kchunk - 1) / gl.kchunk;
+            gl.C = s.ws.whslab; gl.ldc = d.L; gl.slab_stride = nwh;
+            const size_t lds = (size_t)(96 + 128) * 36 * sizeof(float);
+            hipLaunchKernelGGL(ov_dwh_lds_bn_kernel, dim3(gx * gy * gz + bn_blocks), dim3(256), lds, s.st, gl, gx, gy, gz, bn);
+            OV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(ov_wh_combine_kernel, dim3((unsigned)((nwh / 4 + 255) / 256)), dim3(256), 0, s.st, s.ws.whslab, gz, nwh,
+                               c->P + lay.Wh, c->M ? c->M + lay.Wh : nullptr, c->V ? c->V + lay.Wh : nullptr, Gr ? Gr + lay.Wh : nullptr,
+                               apply ? 1 : 0, adam);
+            OV_LAUNCH_CHECK();
+        } else {
             OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
             const int gx = (gw.N + 31) / 32, gy = (gw.M + 31) / 32;
             const size_t lds = (size_t)4 * 16 * 64 * sizeof(float);
