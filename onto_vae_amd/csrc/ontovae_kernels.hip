@@ -428,6 +428,120 @@ __global__ __launch_bounds__(256) void ov_bn_fwd_kernel(const float* __restrict_
     }
 }
 
+// The same at 1024 columns and more (modes 1, 2, 3, 5): ov_bn_fwd_kernel is built for 64 slabs of 128 columns -- its waves
+// split the slabs, then wave 0 alone walks the row twice in 4-B steps (87 us at 8192 columns).  Here the whole workgroup walks the
+// row in every pass, 16 B per lane: slab combine (the order of ov_bn_eval_kernel: four interleaved partial sums, (p0 + p1) +
+// (p2 + p3)) + bias + row sum; squared deviations from the mean; normalise / scale / dropout / ReLU.  A thread re-reads only
+// what it stored itself, so the passes need no barrier except inside the two reductions (lane -> wave -> workgroup, fixed order).
+__device__ __forceinline__ float ov_wg_sum256(float v, float* red) {
+    v = ov_wave_sum(v);
+    if (ov_lane() == 0) red[ov_wave_id()] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(256) void ov_bn_fwd_wide_kernel(const float* __restrict__ slab, int S, int64_t slab_stride,
+                                                            const float* __restrict__ b0, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                                            float* __restrict__ xhat, float* __restrict__ a,
+                                                            float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                            float* __restrict__ stats, int L, int B, int Bglobal, int ldb,
+                                                            int mode, float drop, uint64_t seed, uint64_t rng_off) {
+    __shared__ float red[4];
+    const int l = blockIdx.x, tid = threadIdx.x;
+    float* xr = xhat + (int64_t)l * ldb;
+    float* ar = a + (int64_t)l * ldb;
+    float mean, var;
+    if (mode == 1 || mode == 2) {
+        const float bias = b0[l];
+        float sum = 0.f;
+        for (int b = tid * 4; b < ldb; b += 1024) {
+            const float* src = slab + (int64_t)l * ldb + b;
+            f32x4 p[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) {
+                p[z] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int q = z; q < S; q += 4) p[z] += *reinterpret_cast<const f32x4*>(src + (int64_t)q * slab_stride);
+            }
+            f32x4 h4 = (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h4[j] = b + j < B ? h4[j] + bias : 0.f;          // slab columns >= B were never written
+                sum += h4[j];
+            }
+            *reinterpret_cast<f32x4*>(xr + b) = h4;
+        }
+        mean = ov_wg_sum256(sum, red) / (float)B;
+        float q = 0.f;
+        for (int b = tid * 4; b < ldb; b += 1024) {
+            const f32x4 h4 = *reinterpret_cast<const f32x4*>(xr + b);       // this thread's own stores
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dlt = h4[j] - mean;
+                q += b + j < B ? dlt * dlt : 0.f;
+            }
+        }
+        q = ov_wg_sum256(q, red);
+        if (mode == 2) {
+            if (tid == 0) { stats[l] = mean; stats[L + l] = q; }
+            return;
+        }
+        var = q / (float)B;
+    } else if (mode == 5) {
+        // the ranks' all-gathered (mean, M2, rows) blocks, S of them with stride slab_stride: Chan's combination
+        float n = 0.f, m = 0.f;
+        for (int r = 0; r < S; ++r) {
+            const float nr = stats[r * slab_stride + 2 * L];
+            n += nr;
+            m += nr * stats[r * slab_stride + l];
+        }
+        mean = m / n;
+        float m2 = 0.f;
+        for (int r = 0; r < S; ++r) {
+            const float nr = stats[r * slab_stride + 2 * L];
+            const float dm = stats[r * slab_stride + l] - mean;
+            m2 += stats[r * slab_stride + L + l] + nr * dm * dm;
+        }
+        var = m2 / n;
+    } else {                       // mode 3
+        mean = stats[l];
+        var = stats[L + l];
+    }
+    if (tid == 0) {
+        const float mom = 0.1f;
+        const float nb = (float)Bglobal;
+        rmean[l] = (1.f - mom) * rmean[l] + mom * mean;
+        rvar[l] = (1.f - mom) * rvar[l] + mom * (var * (nb / (nb - 1.f)));
+        if (l == 0) *nbt += 1;
+    }
+    const float invstd = 1.0f / sqrtf(var + 1e-5f);
+    if (tid == 0) {
+        mean_out[l] = mean;
+        invstd_out[l] = invstd;
+    }
+    const float g = gamma[l], be = beta[l];
+    const bool dropping = drop > 0.f;
+    for (int b = tid * 4; b < ldb; b += 1024) {
+        const f32x4 h4 = *reinterpret_cast<const f32x4*>(xr + b);
+        f32x4 xh4, y4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float xh = 0.f, y = 0.f;
+            if (b + j < B) {
+                xh = (h4[j] - mean) * invstd;
+                y = xh * g + be;
+                if (dropping) y *= ov_dropout_scale(drop, seed, rng_off, OV_RNG_DROP, (uint64_t)l * 0x100000000ull + (b + j));
+                y = fmaxf(y, 0.f);
+            }
+            xh4[j] = xh; y4[j] = y;
+        }
+        *reinterpret_cast<f32x4*>(xr + b) = xh4;
+        *reinterpret_cast<f32x4*>(ar + b) = y4;
+    }
+}
+
 // Eval mode (running statistics) at inference batch sizes: plain elementwise work over the whole [L, ldb] matrix instead of
 // one wave walking a feature's row.  Same operations in the same order as mode 0 above (S <= 12: wave z there adds slabs
 // z, z + 4, z + 8 one after the other).
@@ -3011,6 +3125,14 @@ static int ov_bn_fwd(OvStep& s, int S, int mode, int Bglobal, float* stats, uint
     if (mode == 0 && S <= 12 && s.ldb >= 1024) {
         hipLaunchKernelGGL(ov_bn_eval_kernel, dim3((s.ldb / 4 + 255) / 256, d.L), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb,
                            c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, s.ws.a, s.B, s.ldb);
+        OV_LAUNCH_CHECK();
+        return ONTOVAE_OK;
+    }
+    if (mode != 0 && s.ldb >= 1024 && (mode == 3 || mode == 5 || S <= 12)) {
+        hipLaunchKernelGGL(ov_bn_fwd_wide_kernel, dim3(d.L), dim3(256), 0, s.st, s.ws.slab, S, mode == 5 ? (int64_t)(2 * d.L + 1) : (int64_t)d.L * s.ldb,
+                           c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, c->bn_nbt,
+                           s.ws.xhat, s.ws.a, s.ws.bn_mean, s.ws.bn_invstd, stats, d.L, s.B, Bglobal, s.ldb, mode, c->drop, c->seed,
+                           rng_off);
         OV_LAUNCH_CHECK();
         return ONTOVAE_OK;
     }
