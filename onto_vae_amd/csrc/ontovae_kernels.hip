@@ -608,7 +608,26 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
     const int wave = ov_wave_id();
     const int64_t ro = (int64_t)l * ldb;
     float sdy = 0.f, sdyx = 0.f;
-    if (mode < 3) {
+    // from 1024 columns on the row is walked 16 B per lane (ldb is a multiple of 64 and the rows are 256-B aligned); a thread
+    // still re-reads in the second pass only what it stored in the first
+    const bool wide = ldb >= 1024;
+    if (mode < 3 && wide) {
+        for (int b = threadIdx.x * 4; b < ldb; b += 1024) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(a + ro + b);
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xhat + ro + b);
+            f32x4 dy4 = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < daS; ++z) dy4 += *reinterpret_cast<const f32x4*>(da + z * dastride + ro + b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float dy = (b + j < B && a4[j] > 0.f) ? dy4[j] : 0.f;
+                if (drop > 0.f && b + j < B) dy *= ov_dropout_scale(drop, seed, rng_off, OV_RNG_DROP, (uint64_t)l * 0x100000000ull + (b + j));
+                sdy += dy;
+                sdyx += dy * (b + j < B ? x4[j] : 0.f);
+                dy4[j] = dy;
+            }
+            *reinterpret_cast<f32x4*>(dh + ro + b) = dy4;
+        }
+    } else if (mode < 3) {
         for (int b = wave * 64 + lane; b < ldb; b += 256) {
             float dy = 0.f;
             if (b < B) {
@@ -620,6 +639,8 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
             }
             dh[ro + b] = dy;
         }
+    }
+    if (mode < 3) {
         sdy = ov_wave_sum(sdy);
         sdyx = ov_wave_sum(sdyx);
         if (lane == 0) { bn_red[0][wave] = sdy; bn_red[1][wave] = sdyx; }
@@ -645,6 +666,20 @@ __device__ __forceinline__ void ov_bn_bwd_body(const OvBnBwdArgs& q, const int b
     const float nb = (float)Bglobal;
     const float scale = g * is / nb;
     float sdh = 0.f;
+    if (wide && mode != 4) {
+        for (int b = threadIdx.x * 4; b < ldb; b += 1024) {      // the columns this thread wrote above
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dh + ro + b);
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xhat + ro + b);
+            f32x4 v4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = b + j < B ? scale * (nb * d4[j] - gdy - x4[j] * gdyx) : 0.f;
+                sdh += v;
+                v4[j] = v;
+            }
+            *reinterpret_cast<f32x4*>(dh + ro + b) = v4;
+        }
+    } else
     for (int b = wave * 64 + lane; b < ldb; b += 256) {          // the columns this thread wrote above
         float v = 0.f;
         if (b < B) {
