@@ -2507,7 +2507,7 @@ __global__ __launch_bounds__(256) void ov_dwh_bn_kernel(const OvGemm g, int gx, 
     ov_bn_bwd_body(bn, b - gx * gy);
 }
 
-// The same launch from 2048 columns on: dWh as LDS-staged 96 x 128 tiles over split-K slabs of the batch (the 32 x 32 tiles above
+// The same launch from 1024 columns on: dWh as LDS-staged 96 x 128 tiles over split-K slabs of the batch (the 32 x 32 tiles above
 // load MFMA fragments straight from global memory, 32 lines per wave instruction: 169 us at 8192 columns for 4.2 GFLOP), the
 // BatchNorm backward beside it; ov_wh_combine_kernel then adds the slabs in slab order and applies AdamW.
 __global__ __launch_bounds__(256) void ov_dwh_lds_bn_kernel(const OvGemm g, int gx, int gy, int gz, const OvBnBwdArgs bn) {
@@ -4085,8 +4085,8 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     if (!s.side && !(c->flags & ONTOVAE_FLAG_NO_RIDERS)) {
         ov_prof_pair_begin(s.st);
         const int64_t nwh = (int64_t)2 * d.L * d.L;
-        // (from 2048 columns: 49 -> 43 us there, 169 -> 101 at 8192; at 1024 the combine launch costs what the tiles gain)
-        if (s.ldb >= 2048 && (d.L % 4 == 0) && ov_al16(gw.A) && ov_al16(gw.B) && ov_al16(gw.C) && (!apply || (ov_al16(gw.Pm) && ov_al16(gw.Pv)))) {
+        // (with the combine launch: 23 -> 21 us at 1024 columns, 49 -> 28 at 2048, 169 -> 64 at 8192, BatchNorm part vectorised in both)
+        if (s.ldb >= 1024 && (d.L % 4 == 0) && ov_al16(gw.A) && ov_al16(gw.B) && ov_al16(gw.C) && (!apply || (ov_al16(gw.Pm) && ov_al16(gw.Pv)))) {
             OvProfScope prof(ONTOVAE_PHASE_DWH, s.st);
             // 96 x 128 tiles of [2L, L], the batch in split-K slabs: about one workgroup per CU beside the L BatchNorm workgroups
             const int gx = (d.L + 127) / 128, gy = (2 * d.L + 95) / 96;
