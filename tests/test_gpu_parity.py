@@ -391,6 +391,41 @@ def test_train_vs_oracle_batch_sizes(B):
 def test_gradients_vs_oracle(B, flags):
     """Raw gradients (apply_update=0 -> flat buffer) against the oracle's hand-written backward:
     every tensor within 2e-5 of its own scale (fp32 summation-order noise is ~2e-6)."""
+    check_gradients(B, flags)
+
+
+@pytest.mark.parametrize("flags", [0, 1, 16])
+@pytest.mark.parametrize("B", [1100, 2100])
+def test_gradients_vs_oracle_ragged_large_batches(B, flags):
+    """The kernels that take over from 1024 / 2048 columns, on shapes with every kind of tail (1000 genes: K not a multiple of the
+    32-deep step of the two-stage encoder product; 1100 / 2100 rows: padded columns in the whole-workgroup BatchNorm passes, a
+    ragged last split-K slab of the LDS-staged dWh, the LDS-staged da product from 2048 columns): loss and every gradient."""
+    check_gradients(B, flags)
+
+
+def test_fused_steps_large_ragged_batch_vs_oracle():
+    """The same shapes with the update applied (AdamW in the dWh combine kernel, in dW0's chunked kernel): three steps."""
+    from ontovae_oracle import OracleOntoVAE
+    from onto_vae_amd.vae_model import FusedAdamW
+    masks, sd = medium()
+    B, lr, kc = 1100, 1e-3, 1e-4
+    rng = np.random.RandomState(8)
+    o = OracleOntoVAE(masks, 3)
+    o.load_state_dict(sd)
+    model, _ = make_model(masks, 3, sd)
+    opt = FusedAdamW(model, lr=lr)
+    out = torch.zeros(3, 3, device="cuda")
+    want = []
+    for s in range(3):
+        x = np.log1p(rng.poisson(0.5, size=(B, 1000))).astype(np.float32)
+        eps = rng.standard_normal((B, 60)).astype(np.float32)
+        want.append(o.train_step(x, eps, lr, kc))
+        model._engine.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), kc, opt.next_hyper(), out[s])
+    np.testing.assert_allclose(out.cpu().numpy(), np.array(want, dtype=np.float32), rtol=REL)
+    check_params(hip_state(model), o.state_dict(), 3 * lr, rtol=2e-4, atol=2e-6, outliers=0.01)
+
+
+def check_gradients(B, flags):
     from ontovae_oracle import OracleOntoVAE
     masks, sd = medium()
     rng = np.random.RandomState(100 + B)
