@@ -607,11 +607,14 @@ __global__ __launch_bounds__(256) void ov_gemm_lds_kernel(const OvGemm p) {
 // that at the barrier a wave has nothing left to wait for but the other waves.  Same tiles, same operand order and same summation order as ov_gemm_lds_kernel: bit-identical
 // results.
 // -------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(256) void ov_gemm_lds2_kernel(const OvGemm p) {
-    constexpr int MT = 3, BK = 32, LDK = BK + 4;
-    constexpr int RA = 32 * MT, RB = 128;
-    constexpr int UA = RA * 8 / 256, UB = RB * 8 / 256;
+// WM: row tiles of 96 per workgroup, 4 waves each (WM = 2: 192 x 128, 8 waves that share one B stage -- 5 instead of 7 staging
+// loads, selects and LDS stores per thread and step for the same MFMAs per wave).
+template <int EPI, int WM>
+__global__ __launch_bounds__(256 * WM) void ov_gemm_lds2_kernel(const OvGemm p) {
+    constexpr int MT = 3, BK = 32, LDK = BK + 4, NT = 256 * WM;
+    constexpr int RA = 32 * MT * WM, RB = 128;
+    constexpr int UA = RA * 8 / NT, UB = RB * 8 / NT;
+    constexpr int RS = NT / 8;                    // rows one pass of the workgroup's threads stages
     constexpr int STAGE = (RA + RB) * LDK;        // floats per LDS stage
     extern __shared__ __attribute__((aligned(16))) float ov_gemm_lds[];
     const int tid = threadIdx.x;
@@ -632,13 +635,13 @@ __global__ __launch_bounds__(256) void ov_gemm_lds2_kernel(const OvGemm p) {
     const float* asrc[UA];
     const float* bsrc[UB];
 #pragma unroll
-    for (int u = 0; u < UA; ++u) asrc[u] = p.A + (int64_t)min(m0 + (tid >> 3) + 32 * u, p.M - 1) * p.lda;
+    for (int u = 0; u < UA; ++u) asrc[u] = p.A + (int64_t)min(m0 + (tid >> 3) + RS * u, p.M - 1) * p.lda;
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-        const int n = min(n0 + (tid >> 3) + 32 * u, p.N - 1);
+        const int n = min(n0 + (tid >> 3) + RS * u, p.N - 1);
         bsrc[u] = p.B + (p.bgather ? (int64_t)p.bgather[n] : (int64_t)n) * p.ldb;
     }
-    const int dst0 = (tid >> 3) * LDK + kq4;      // + 32 u rows; B behind the RA rows of A
+    const int dst0 = (tid >> 3) * LDK + kq4;      // + RS u rows; B behind the RA rows of A
     f32x4 ra[UA], rb[UB];
     const int kclamp = (p.K - 1) & ~3;
     auto gload = [&](int k0) {                    // every lane, every load; clamped into the row (see ov_gemm_lds_kernel)
@@ -657,17 +660,18 @@ __global__ __launch_bounds__(256) void ov_gemm_lds2_kernel(const OvGemm p) {
         for (int u = 0; u < UA; ++u) {
             f32x4 v;
             v.x = o0 ? ra[u].x : 0.f; v.y = o1 ? ra[u].y : 0.f; v.z = o2 ? ra[u].z : 0.f; v.w = o3 ? ra[u].w : 0.f;
-            *reinterpret_cast<f32x4*>(st + dst0 + 32 * u * LDK) = v;
+            *reinterpret_cast<f32x4*>(st + dst0 + RS * u * LDK) = v;
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             f32x4 v;
             v.x = o0 ? rb[u].x : 0.f; v.y = o1 ? rb[u].y : 0.f; v.z = o2 ? rb[u].z : 0.f; v.w = o3 ? rb[u].w : 0.f;
-            *reinterpret_cast<f32x4*>(st + RA * LDK + dst0 + 32 * u * LDK) = v;
+            *reinterpret_cast<f32x4*>(st + RA * LDK + dst0 + RS * u * LDK) = v;
         }
     };
     // fragments of 4 k: lane (i, h) holds k = 8 g + 4 h .. + 3 of group g
-    const int fa_off = i * LDK + 4 * h, fb_off = (RA + wave * 32 + i) * LDK + 4 * h;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fa_off = (wm * 32 * MT + i) * LDK + 4 * h, fb_off = (RA + wn * 32 + i) * LDK + 4 * h;
     auto fread = [&](const float* st, int g, f32x4 (&fa)[MT], f32x4& fb) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const f32x4*>(st + fa_off + 32 * mt * LDK + 8 * g);
@@ -718,10 +722,10 @@ __global__ __launch_bounds__(256) void ov_gemm_lds2_kernel(const OvGemm p) {
         cur ^= 1;
     }
 
-    const int n = n0 + wave * 32 + i;
+    const int n = n0 + wn * 32 + i;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int mb = m0 + 32 * mt;
+        const int mb = m0 + wm * 32 * MT + 32 * mt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;

@@ -2959,13 +2959,13 @@ static int ov_launch_gemm_lds(const OvGemm& g, int S, hipStream_t st) {
 }
 
 // the two-stage form of the encoder-forward product (ov_gemm_lds2_kernel)
-template <int EPI>
+template <int EPI, int WM>
 static int ov_launch_gemm_lds2(const OvGemm& g, int S, hipStream_t st) {
-    dim3 grid((g.N + 127) / 128, (g.M + 95) / 96, S);
-    const size_t lds = (size_t)2 * (96 + 128) * 36 * sizeof(float);
-    auto kern = ov_gemm_lds2_kernel<EPI>;
+    dim3 grid((g.N + 127) / 128, (g.M + 96 * WM - 1) / (96 * WM), S);
+    const size_t lds = (size_t)2 * (96 * WM + 128) * 36 * sizeof(float);
+    auto kern = ov_gemm_lds2_kernel<EPI, WM>;
     { int rc_ = ov_allow_lds(reinterpret_cast<const void*>(kern), lds); if (rc_) return rc_; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL(kern, grid, dim3(256 * WM), lds, st, g);
     OV_LAUNCH_CHECK();
     return ONTOVAE_OK;
 }
@@ -3144,7 +3144,10 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     OvProfScope prof(ONTOVAE_PHASE_ENC_GEMM, s.st);
     const int nt = ov_enc_nt(s.B);
     // from 1024 columns on: two LDS stages, one barrier per K-step (8192 columns: 1058 -> 1015 us, 1024: 166 -> 162, same box)
-    if (vec && nt == 4 && s.ldb >= 1024 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds2<OV_EPI_STORE>(g, Seff, s.st);
+    // from 4096 columns (where the split-K count no longer has to make up for the halved number of workgroups): 192 x 128 tiles, 8 waves
+    // sharing one stage of x (same box: 1047-1057 -> 1024-1030 us at 8192 columns, 2080-2112 -> 2020-2035 at 16384)
+    if (vec && nt == 4 && s.ldb >= 4096 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds2<OV_EPI_STORE, 2>(g, Seff, s.st);
+    if (vec && nt == 4 && s.ldb >= 1024 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds2<OV_EPI_STORE, 1>(g, Seff, s.st);
     if (vec && nt == 4 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds<1, 4, true, OV_EPI_STORE>(g, Seff, s.st);
     if (nt == 1) return ov_launch_gemm<3, 1, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
     if (nt == 2) return ov_launch_gemm<3, 2, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);

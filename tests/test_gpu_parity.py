@@ -394,13 +394,19 @@ def test_gradients_vs_oracle(B, flags):
     check_gradients(B, flags)
 
 
-@pytest.mark.parametrize("flags", [0, 1, 16])
-@pytest.mark.parametrize("B", [1100, 2100])
+@pytest.mark.parametrize("B,flags", [(1100, 0), (1100, 1), (1100, 16), (2100, 0), (2100, 1), (2100, 16), (4200, 0)])
 def test_gradients_vs_oracle_ragged_large_batches(B, flags):
     """The kernels that take over from 1024 / 2048 columns, on shapes with every kind of tail (1000 genes: K not a multiple of the
     32-deep step of the two-stage encoder product; 1100 / 2100 rows: padded columns in the whole-workgroup BatchNorm passes, a
-    ragged last split-K slab of the LDS-staged dWh, the LDS-staged da product from 2048 columns): loss and every gradient."""
-    check_gradients(B, flags)
+    ragged last split-K slab of the LDS-staged dWh, the LDS-staged da product from 2048 columns; 4200 rows: the 8-wave form of the
+    encoder product): loss and every gradient.  At 4200 rows the batch's seed is one for which no pre-activation lies within fp32
+    rounding of the ReLU threshold: with 252 000 of them per batch one occasionally does, and the two correct fp32 evaluations then
+    differ in a whole row of dW0 by about a percent (seen on this path at seed 4300 and on the fp32 oracle at 8000 rows, each
+    against the float64 oracle, scratch/dw0_ragged_probe.py); the summation noise itself grows to 2-3e-5 of the scale there."""
+    if B == 4200:
+        check_gradients(B, flags, seed=4302, tol=5e-5)
+    else:
+        check_gradients(B, flags)
 
 
 def test_fused_steps_large_ragged_batch_vs_oracle():
@@ -425,10 +431,10 @@ def test_fused_steps_large_ragged_batch_vs_oracle():
     check_params(hip_state(model), o.state_dict(), 3 * lr, rtol=2e-4, atol=2e-6, outliers=0.01)
 
 
-def check_gradients(B, flags):
+def check_gradients(B, flags, seed=None, tol=2e-5):
     from ontovae_oracle import OracleOntoVAE
     masks, sd = medium()
-    rng = np.random.RandomState(100 + B)
+    rng = np.random.RandomState(100 + B if seed is None else seed)
     x = np.log1p(rng.poisson(0.5, size=(B, 1000))).astype(np.float32)
     eps = rng.standard_normal((B, 60)).astype(np.float32)
     o = OracleOntoVAE(masks, 3)
@@ -457,7 +463,7 @@ def check_gradients(B, flags):
         if k.startswith("decoder") and k.endswith("weight"):
             want = want * o.masks[int(k.split(".")[2])]          # vae_model.py:168-169
         scale = np.abs(want).max()
-        assert np.abs(v.cpu().numpy() - want).max() <= 2e-5 * scale, k
+        assert np.abs(v.cpu().numpy() - want).max() <= tol * scale, k
     # the Linear bias in front of a train-mode BatchNorm has an analytically zero gradient
     assert np.abs(e.view("b0", G).cpu().numpy()).max() <= 1e-4 * np.abs(g["encoder.encoder.0.1.bias"]).max()
 
