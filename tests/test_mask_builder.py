@@ -40,6 +40,21 @@ def test_links_reproduce_reference_masks(name):
     assert np.array_equal(same.rowptr, plan.rowptr) and np.array_equal(same.colidx, plan.colidx)
 
 
+@pytest.mark.parametrize("name", ["graph_small", "graph_deep"])
+def test_encoder_links_reproduce_reference_masks(name):
+    """The encoder masks of OntoEncVAE (ontobj.py:394-404) on random DAGs with links that skip levels, a trimmed-away parent and a
+    duplicated parent entry: bit-exact against what the reference's code made of the same graph."""
+    from onto_vae_amd.mask_builder import encoder_links_from_graph
+    graph, annot, genes, dec = load(name)
+    z = np.load(os.path.join(GOLDEN, f"masks_{name}.npz"), allow_pickle=False)
+    want = [z[f"emask{i}"].astype(np.int64) for i in range(len(dec))]
+    links, shapes = encoder_links_from_graph(graph, annot, genes)
+    pm = PackedMasks(links, shapes)
+    assert len(pm) == len(want) and len(links[0]) == sum(int(m.sum()) for m in want) == sum(int(m.sum()) for m in dec)
+    for i, m in enumerate(want):
+        assert pm.shapes[i] == m.shape and np.array_equal(pm[i], m), i
+
+
 def test_create_masks_on_ontobj_like_object_and_model():
     graph, annot, genes, want = load("graph_small")
 

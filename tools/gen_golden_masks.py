@@ -2,7 +2,7 @@
 """Golden vectors for onto_vae_amd/mask_builder.py, made by the REFERENCE's own mask code.
 
 onto_vae/ontobj.py cannot be imported here (it imports goatools at module level, which this image lacks), so the two
-methods that build the masks, Ontobj.create_masks and Ontobj._decoder_masks, are lifted out of the reference file by
+methods that build the masks, Ontobj.create_masks, Ontobj._decoder_masks and Ontobj._encoder_masks, are lifted out of the reference file by
 their AST nodes and executed unchanged on a minimal object; utils.create_binary_matrix is imported normally.  Nothing
 of the reference is written into the repository: the fixture holds the synthetic graph (inputs) and the masks the
 reference code produced (expected outputs).
@@ -79,6 +79,12 @@ def main():
               "genes": np.array(genes), "nmask": np.int64(len(masks))}
         for i, m in enumerate(masks):
             fx[f"mask{i}"] = np.asarray(m).astype(np.uint8)
+        # the encoder masks of OntoEncVAE from the same graph (Ontobj.create_masks' else branch, _encoder_masks)
+        obj.create_masks(1000, 30, "encoder")
+        emasks = obj.masks["1000_30"]["encoder"]
+        for i, m in enumerate(emasks):
+            fx[f"emask{i}"] = np.asarray(m).astype(np.uint8)
+        print("   encoder:", [np.asarray(m).shape for m in emasks])
         path = os.path.join(a.out, f"masks_{name}.npz")
         np.savez_compressed(path, **fx)
         print(path, [m.shape for m in masks], int(sum(np.asarray(m).sum() for m in masks)), "links")
