@@ -245,6 +245,36 @@ def test_vae_dropout_on_gradients_match_oracle_with_same_masks():
         assert torch.equal(u, v)
 
 
+def test_vae_gradients_large_ragged_batch_with_dropout():
+    """1100 rows (1152 padded columns): the 16-B-per-lane passes of the BatchNorm backward, which the dense blocks share with the
+    OntoVAE encoder, with dropout masks on and padded columns in play: loss and every gradient against the oracle."""
+    import philox_oracle as ph
+    from vae_oracle import OracleVAE
+    G, enc, dec, Z, B = 310, [64, 40], [48], 24, 1100
+    drop, z_drop = 0.2, 0.5
+    rng = np.random.default_rng(15)
+    o = OracleVAE(G, enc, dec, Z)
+    sd = random_state(o, rng)
+    o.load_state_dict(sd)
+    x = rng.gamma(2.0, 1.0, (B, G)).astype(np.float32)
+    eps = rng.standard_normal((B, Z)).astype(np.float32)
+    m = hip_model(o, sd, drop, z_drop)
+    e = m._engine
+    off = e.rng_offset + 1
+    scales = {"mu": ph.dropout_scale(z_drop, e.seed, off, ph.STREAM_ZDROP_MU, Z, B),
+              "logvar": ph.dropout_scale(z_drop, e.seed, off, ph.STREAM_ZDROP_LV, Z, B)}
+    for k, (pre, _, w) in enumerate(o.blocks()):
+        scales[pre] = ph.dropout_scale(drop, e.seed, off ^ ((k + 1) << 48), ph.STREAM_DROP, w, B)
+    want = o.gradients(x, eps, 1e-3, scales)
+    out = torch.zeros(3, device=e.device)
+    e.train_step(torch.as_tensor(x), None, torch.as_tensor(eps), 1e-3, None, out, apply_update=False)
+    np.testing.assert_allclose(out.cpu().numpy(), [float(v) for v in want[:3]], rtol=REL)
+    g = grads_by_name(m)
+    gmax = max(np.abs(v).max() for v in want[3].values())
+    for k, w in want[3].items():
+        assert np.abs(g[k] - w).max() <= 5e-5 * np.abs(w).max() + 2e-6 * gmax, k
+
+
 def test_vae_train_model_protocol(tmp_path, capsys):
     """train_model (vae_model.py:1082-1140): split, loaders, printed lines, best-model checkpoint in the reference's format."""
     from onto_vae_amd import VAE
