@@ -257,7 +257,7 @@ def test_dense_packed_round_trip_on_device(case):
 
 
 # ------------------------------------------------------------------------------ dropout on
-@pytest.mark.parametrize("B", [48, 200])
+@pytest.mark.parametrize("B", [48, 200, 1100])          # 1100: the whole-workgroup BatchNorm passes draw the same masks
 def test_dropout_on_gradients_vs_oracle(B):
     """The reference's default configuration (drop = 0.2, z_drop = 0.5, vae_model.py:40).  The kernels draw their masks from
     Philox4x32-10 keyed by (seed, rng_offset, stream, element); oracle/philox_oracle.py restates that keying on the host, the
