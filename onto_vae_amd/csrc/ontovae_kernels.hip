@@ -1172,7 +1172,9 @@ __global__ __launch_bounds__(256) void ov_sell_refresh_kernel(const OvRefresh rf
 //   FWD: out = bias + sum w * panel[idx]      BWD: out = D (gene part, from HBM) + sum w * dpanel[idx]
 // -------------------------------------------------------------------------------------------------
 #ifndef OV_CHAIN_DEPTH
-#define OV_CHAIN_DEPTH 3     // records in flight per wave (19 registers each; 16 waves per CU leave 128 per lane)
+#define OV_CHAIN_DEPTH 1     // records in flight per wave beyond the current one (19 registers each; 16 waves per CU leave 128 per lane).
+                             // Measured, forward + backward chain: 47.9 us at depth 3, 46.3 at 2, 44.9 at 1, 48.9 at 4 (128 columns); 70.4 / 69.4 /
+                             // 68.9 / 72.2 at 1024 columns: the records are L2 hits, and the registers of a deeper ring cost more than its latency cover buys
 #endif
 struct OvRec {          // chunk 0 of one lane of a slice
     int node, info;
