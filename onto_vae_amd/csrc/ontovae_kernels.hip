@@ -1098,16 +1098,20 @@ __global__ __launch_bounds__(256) void ov_dec_fwd_kernel(const int32_t* __restri
 // the gene layer and the weight gradient.
 // -------------------------------------------------------------------------------------------------
 #define OV_MAX_LEVELS 64
-// The chain as a flat list of steps that every wave walks: in step q a wave owns slice base[q] + wave if that
-// is below end[q]; a step that opens a new level is marked in bit 30 of base[q] (workgroup barrier first).
-#define OV_MAX_STEPS 240
+// The chain as a flat list of steps that every wave walks, one packed word per step: in step q a wave owns slice
+// base + wave if wave < count (count = 1 .. 16 slices of the step, bits 24-29; base = bits 0-23); a step that opens a new
+// level is marked in bit 30 (workgroup barrier first).  The list lives in the kernel arguments, so a step's word is a scalar
+// load with a memory round trip behind it: the kernel requests step q + 1's word while it works on step q (two dependent
+// scalar loads at the head of every step, base and end in separate arrays, were 2 of the chain's 20 us at 128 columns).
+#define OV_MAX_STEPS 480
 struct OvSteps {
     int n;
     int last_slice;            // n_slices - 1: where requests beyond the schedule are clamped to
-    int base[OV_MAX_STEPS];
-    int end[OV_MAX_STEPS];
+    int pk[OV_MAX_STEPS];
 };
 #define OV_STEP_NEW_LEVEL (1 << 30)
+#define OV_STEP_BASE(w) ((w) & 0xFFFFFF)
+#define OV_STEP_COUNT(w) (((w) >> 24) & 63)
 // false if the schedule does not fit (the caller then launches level by level)
 static bool ov_make_steps(const ontovae_sell_t& f, OvSteps* st) {
     st->n = 0;
@@ -1116,8 +1120,8 @@ static bool ov_make_steps(const ontovae_sell_t& f, OvSteps* st) {
         const int first = f.level_first[li], count = f.level_count[li];
         for (int j = 0; 16 * j < count; ++j) {
             if (st->n >= OV_MAX_STEPS) return false;
-            st->base[st->n] = (first + 16 * j) | ((j == 0 && st->n > 0) ? OV_STEP_NEW_LEVEL : 0);
-            st->end[st->n] = first + count;
+            if (first + 16 * j > 0xFFFFFF) return false;
+            st->pk[st->n] = (first + 16 * j) | (std::min(16, count - 16 * j) << 24) | ((j == 0 && st->n > 0) ? OV_STEP_NEW_LEVEL : 0);
             ++st->n;
         }
     }
@@ -1138,20 +1142,13 @@ __device__ __forceinline__ float ov_group_sum(float v) {
 
 template <int BT>
 __device__ __forceinline__ void ov_group_sum_rt(float (&acc)[BT], int lg) {
-#pragma unroll
-    for (int j = 0; j < BT; ++j) {
-        float v = acc[j];
-        switch (lg) {                      // wave-uniform
-            case 0: break;
-            case 1: v = ov_group_sum<1>(v); break;
-            case 2: v = ov_group_sum<2>(v); break;
-            case 3: v = ov_group_sum<3>(v); break;
-            case 4: v = ov_group_sum<4>(v); break;
-            case 5: v = ov_group_sum<5>(v); break;
-            default: v = ov_group_sum<6>(v); break;
-        }
-        acc[j] = v;
+#define OV_GS_CASE(N) case N: _Pragma("unroll") for (int j = 0; j < BT; ++j) acc[j] = ov_group_sum<N>(acc[j]); break;
+    switch (lg) {                          // wave-uniform; ONE branch tree for the BT columns
+        case 0: break;
+        OV_GS_CASE(1) OV_GS_CASE(2) OV_GS_CASE(3) OV_GS_CASE(4) OV_GS_CASE(5)
+        default: _Pragma("unroll") for (int j = 0; j < BT; ++j) acc[j] = ov_group_sum<6>(acc[j]); break;
     }
+#undef OV_GS_CASE
 }
 
 // Refresh of the SELL-ordered weight copies from the parameter buffer (start of every pass).
@@ -1239,14 +1236,14 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
     // gathers) is far shorter than the memory round trip of its record.  Every request is unconditional (a
     // wave without a slice in some step, or past the end of the schedule, re-reads a clamped slice) so that
     // the number of loads between a request and its use is the same on every path and the waits stay exact.
-    auto request = [&](OvRec& r, int q) {
-        const int qq = min(q, st.n - 1);
-        const int sl = min(min((st.base[qq] & ~OV_STEP_NEW_LEVEL) + wave, st.end[qq] - 1), st.last_slice);
+    static_assert(OV_CHAIN_DEPTH == 1, "the step loop below keeps one record in flight");
+    auto request = [&](OvRec& r, int word) {      // word: the packed step the record is for
+        const int sl = min(OV_STEP_BASE(word) + min(wave, OV_STEP_COUNT(word) - 1), st.last_slice);
         ov_rec_load<BWD>(r, sl, lane, snode, sinfo, chunk0, sidx, sw, sbias, SINGLE ? 1 : 0);
     };
-    OvRec rec[OV_CHAIN_DEPTH];
-#pragma unroll
-    for (int t = 0; t < OV_CHAIN_DEPTH; ++t) request(rec[t], t);
+    OvRec rec;
+    int next_word = st.pk[0];
+    request(rec, next_word);
 
     // prologue: the rows the chain starts from, HBM -> LDS.  FWD: level 0 (z).  BWD: every panel row
     // (the gene layer's contribution, written by the gene backward kernel).
@@ -1265,23 +1262,25 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    for (int q0 = 0; q0 < st.n; q0 += OV_CHAIN_DEPTH) {
-#pragma unroll
-        for (int t = 0; t < OV_CHAIN_DEPTH; ++t) {
-            const int q = q0 + t;
-            if (q < st.n) {                          // uniform over the workgroup
-                const int bq = st.base[q];
+    for (int q = 0; q < st.n; ++q) {
+        {
+            {
+                const int bq = next_word;
+                next_word = st.pk[min(q + 1, st.n - 1)];           // scalar load; consumed by the request at the end of this step
                 if ((bq & OV_STEP_NEW_LEVEL) && !(dbg & 4)) {
                     // LDS writes of the level must land before the next level reads them
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
-                const int sl = (bq & ~OV_STEP_NEW_LEVEL) + wave;
-                if (sl < st.end[q] && !(dbg & 2)) {                // uniform over the wave
-                    const OvRec& cur = rec[t];
+                const int sl = OV_STEP_BASE(bq) + wave;
+                if (wave < OV_STEP_COUNT(bq) && !(dbg & 2)) {      // uniform over the wave
+                    const OvRec& cur = rec;
                     const int cnt = cur.info & 0xFFFF;
                     const int lg = __builtin_amdgcn_readfirstlane((cur.info >> 16) & 7);
-                    const int width = __builtin_amdgcn_readfirstlane((cur.info >> 20) & 15);   // entries per lane of this slice
+                    // all 8 entries of the chunk whatever the slice's width (padding slots: weight 0, a row the slice reads anyway): the
+                    // eight gathers and FMAs behind wave-uniform `e < width` branches were slower than the LDS reads they saved
+                    // (forward + backward chain 45.2 -> 41.9 us at 128 columns, 68.8 -> 65.3 at 1024)
+                    constexpr int width = 8;
                     const bool writer = (cur.info >> 24) & 1;
                     float acc[BT];
 #pragma unroll
@@ -1328,10 +1327,10 @@ __device__ __forceinline__ void ov_dec_chain_body(const OvChainArgs& ca, const O
                         ov_stv<BT>(ov_panel + (int64_t)cur.node * BT, acc);
                         // and to the feature-major matrix in HBM, for the gene layer and the weight gradient: issued here, the
                         // 16-B pieces drain under the rest of the chain (as one pass at the end they were 7.5 of the kernel's 28 us)
-                        if (!(dbg & 8) && sl % ca.nrep == rep) ov_stv<BT>(glob + (int64_t)cur.node * ldb + b0, acc);
+                        if (!(dbg & 8) && (sl & (ca.nrep - 1)) == rep) ov_stv<BT>(glob + (int64_t)cur.node * ldb + b0, acc);
                     }
                 }
-                if (!(dbg & 1)) request(rec[t], q + OV_CHAIN_DEPTH);     // this ring slot's next record
+                if (!(dbg & 1)) request(rec, next_word);     // the next step's record
             }
         }
     }
@@ -3335,7 +3334,8 @@ static int ov_sell_refresh(OvStep& s, hipStream_t st) {
 // replicas of every column group's chain workgroup (ov_dec_chain_body): up to half of the CUs (the riders of the chain
 // launches take the rest; every workgroup of such a launch reserves the panel's LDS, so it has a CU to itself), at most 4
 // (8 buy nothing more)
-static int ov_chain_replicas(int nchain) { return std::max(1, std::min(4, 128 / std::max(nchain, 1))); }
+// (a power of two: the kernel picks a replica's slices with a mask, not a division)
+static int ov_chain_replicas(int nchain) { const int r = std::max(1, std::min(4, 128 / std::max(nchain, 1))); return r >= 4 ? 4 : (r >= 2 ? 2 : 1); }
 
 // refreshed = the packed weight copies were already refreshed for this pass (on the side stream, joined)
 static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
