@@ -3144,12 +3144,11 @@ static int ov_enc_gemm(OvStep& s, int* S_out) {
     g.dbg = OV_DBG((s.c->flags >> 18) & 3);
     OvProfScope prof(ONTOVAE_PHASE_ENC_GEMM, s.st);
     const int nt = ov_enc_nt(s.B);
-    // from 1024 columns on: two LDS stages, one barrier per K-step (8192 columns: 1058 -> 1015 us, 1024: 166 -> 162, same box)
+    // two LDS stages, one barrier per K-step (8192 columns: 1058 -> 1015 us, 1024: 166 -> 162, 512: 84 -> 82, 128: 26.9 -> 26.5, same box)
     // from 4096 columns (where the split-K count no longer has to make up for the halved number of workgroups): 192 x 128 tiles, 8 waves
     // sharing one stage of x (same box: 1047-1057 -> 1024-1030 us at 8192 columns, 2080-2112 -> 2020-2035 at 16384)
     if (vec && nt == 4 && s.ldb >= 4096 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds2<OV_EPI_STORE, 2>(g, Seff, s.st);
-    if (vec && nt == 4 && s.ldb >= 1024 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds2<OV_EPI_STORE, 1>(g, Seff, s.st);
-    if (vec && nt == 4 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds<1, 4, true, OV_EPI_STORE>(g, Seff, s.st);
+    if (vec && nt == 4 && !OV_DBG((s.c->flags >> 20) & 1)) return ov_launch_gemm_lds2<OV_EPI_STORE, 1>(g, Seff, s.st);
     if (nt == 1) return ov_launch_gemm<3, 1, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
     if (nt == 2) return ov_launch_gemm<3, 2, 4, 1, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
     if (OV_DBG((s.c->flags >> 14) & 1)) return ov_launch_gemm<3, 4, 4, 2, true, true, OV_EPI_STORE>(g, Seff, vec, s.st);
