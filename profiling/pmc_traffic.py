@@ -6,7 +6,7 @@ FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRITE_SIZE is taken
 """
 import csv, collections, datetime, json, subprocess, sys
 
-PHASE_OF = {"ov_dw0_kernel": "dw0", "ov_gemm_lds_kernel": "enc_gemm", "ov_gene_cb_kernel": "dec_fwd_gene",
+PHASE_OF = {"ov_dw0_kernel": "dw0", "ov_gemm_lds_kernel": "enc_gemm", "ov_gemm_lds2_kernel": "enc_gemm", "ov_gene_cb_kernel": "dec_fwd_gene",
             "ov_bwd_gene_cb_kernel": "dec_bwd_gene", "ov_bwd_gene_term": "dec_bwd_gene", "ov_chain_bwd_finish_kernel": "dec_bwd",
             "ov_dec_chain_kernel": "dec_fwd_terms", "ov_chain_fwd_refresh_kernel": "dec_fwd_terms", "ov_latent_bwd_kernel": "latent_bwd", "ov_da_gemm_kernel": "da_gemm",
             "ov_dwh_bn_kernel": "dwh", "ov_bn_fwd_kernel": "bn_fwd", "ov_reparam_kernel": "reparam", "ov_gemm_kernel<1, 1, 4, 4": "heads"}
