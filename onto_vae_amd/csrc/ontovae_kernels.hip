@@ -3212,7 +3212,12 @@ static int ov_heads_fwd(OvStep& s) {
 }
 
 static int ov_fused_bt(const ontovae_ctx_t* c);
-#define OV_CHAIN_MAX_LDB 2048
+#define OV_CHAIN_MAX_LDB 2048            // backward, and forward passes whose level kernels write the activities
+#define OV_CHAIN_FWD_MAX_LDB 4096        // every other forward pass
+// below this many columns the gene backward also writes the panel rows of D column-group-major for the backward chain (us per step with /
+// without that copy: 185.3 / 191.9 at 128 columns, 279.1 / 283.1 at 256, 451.0 / 448.6 at 512, 799.8 / 777.2 at 1024: the 16-B pieces
+// cost the gene backward 23 us to write at 1024 columns and the chain 6 us to read from the feature-major matrix instead)
+#define OV_BLK_MAX_LDB 512
 // the forward pass of this step runs the fused term chain: the gene layer's copy is then refreshed by riders of that launch
 // (25 us on a fraction of the chip) instead of in front of it
 static bool ov_gene_refresh_rides(const OvStep& s) {
@@ -3341,10 +3346,12 @@ static int ov_dec_forward_terms(OvStep& s, bool refreshed = false) {
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     // The chain kernel keeps a [C][bt] panel in LDS, so a workgroup carries 4 columns and a large batch becomes many rounds
-    // of latency-bound workgroups; from 2048 columns on one launch per level over the whole batch is faster
-    // (B = 4096: 121 us against 203 us; B = 1024: 75 against 51)
+    // of latency-bound workgroups; from 4096 columns on one launch per level over the whole batch is faster
+    // (us, chain against levels: 31 / 75 at 1024 columns, 53 / 70 at 2048, 117 / 105 at 4096), from OV_CHAIN_MAX_LDB columns
+    // when the level kernels also write the activities (ov_fm_fused)
     // (dropout on the term layers' outputs lives in the per-level kernels only)
-    const int bt = (s.ldb >= OV_CHAIN_MAX_LDB || s.tdrop.rate > 0.f) ? 0 : ov_fused_bt(c);
+    const int chain_max = s.fm_out ? OV_CHAIN_MAX_LDB : OV_CHAIN_FWD_MAX_LDB;
+    const int bt = (s.ldb >= chain_max || s.tdrop.rate > 0.f) ? 0 : ov_fused_bt(c);
     int rc;
     if (!refreshed && (rc = ov_sell_refresh(s, s.st))) return rc;      // also the gene layer's CSR-ordered copy, whatever the path
     if (bt == 0) {
@@ -3499,15 +3506,15 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
     }
     const float* vals = c->P + c->lay.dec_vals;
     float* blk = nullptr;
-    // as in the forward pass: from OV_CHAIN_MAX_LDB columns on, one launch per level over the whole batch instead of the LDS
-    // chain (a workgroup of the chain carries 4 columns: many rounds of latency-bound workgroups), and the gene backward
-    // then has no column-group-major copy of D to write
-    // (8192 columns: gene backward 1.37 -> 1.27 ms, term part 270 -> 204 us; 2048: 349 + 65 -> 320 + 85 us)
-    const bool per_level = s.ldb >= OV_CHAIN_MAX_LDB && !fin;
+    // as in the forward pass: from 4096 columns on, one launch per level over the whole batch instead of the LDS
+    // chain (a workgroup of the chain carries 4 columns: many rounds of latency-bound workgroups)
+    // (8192 columns: term part 270 -> 204 us; 2048: 77 us as a chain reading the feature-major D, 87 us per level)
+    const bool per_level = s.ldb >= OV_CHAIN_FWD_MAX_LDB && !fin;
     if (!(c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES)) {
         OvProfScope prof(ONTOVAE_PHASE_DEC_BWD_GENE, s.st);
         const int ncb = s.ldb / 32, ntiles = (d.C + 31) / 32;
-        if (bt == 4 && !per_level) blk = s.ws.dblk;           // the chain's workgroups take 4 columns each: hand them contiguous pieces
+        // the chain's workgroups take 4 columns each: hand them contiguous pieces while that copy is cheap to write
+        if (bt == 4 && !per_level && s.ldb < OV_BLK_MAX_LDB) blk = s.ws.dblk;
         // waves per SIMD: the kernel needs 5 to cover its latencies while 4 column blocks are all there is (22.1 us at 128
         // columns against 24.7 with 4); once every XCD works through many blocks, fewer waves leave more of its L2 to each
         // (1024 columns: 170 us with 4 against 176 with 5; 8192: 1.40 ms with 3, 1.43 with 4, 1.52 with 5)
