@@ -197,13 +197,14 @@ struct OvWs {
 
 // Encoder forward GEMM (M = L, N = B, K = G): wave tile 96 x (32 NT), four waves of a workgroup split
 // its K range, and enough workgroups along K to give every CU one (they each keep one wave per SIMD)
+#define OV_ENC_TILES2 16
 static int ov_enc_nt(int B) { return B <= 32 ? 1 : (B <= 64 ? 2 : 4); }
 static int ov_enc_splitk(int L, int B, int G) {
     const int tiles = ((L + 95) / 96) * ((B + 32 * ov_enc_nt(B) - 1) / (32 * ov_enc_nt(B)));
     // one workgroup per CU while the split is what fills the chip (training batches); with many output tiles (inference
     // batches) two per CU hide each other's latency: 523 instead of 587 us at B = 4096
-    const int target = tiles >= 64 ? 512 : 256;
-    int s = (target + tiles - 1) / tiles;
+    const int target = tiles >= OV_ENC_TILES2 ? 512 : 256;
+    int s = std::max(1, target / tiles);          // never more workgroups than the target: the extra ones would be a second round
     const int smax = std::max(1, G / 256);
     return std::max(1, std::min(std::min(s, 128), smax));
 }
@@ -3160,13 +3161,13 @@ static int ov_bn_fwd(OvStep& s, int S, int mode, int Bglobal, float* stats, uint
     const ontovae_ctx_t* c = s.c;
     const ontovae_dims_t& d = c->dims;
     OvProfScope prof(ONTOVAE_PHASE_BN_FWD, s.st);
-    if (mode == 0 && S <= 12 && s.ldb >= 1024) {
+    if (mode == 0 && S <= 16 && s.ldb >= 1024) {
         hipLaunchKernelGGL(ov_bn_eval_kernel, dim3((s.ldb / 4 + 255) / 256, d.L), dim3(256), 0, s.st, s.ws.slab, S, (int64_t)d.L * s.ldb,
                            c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, s.ws.a, s.B, s.ldb);
         OV_LAUNCH_CHECK();
         return ONTOVAE_OK;
     }
-    if (mode != 0 && s.ldb >= 1024 && (mode == 3 || mode == 5 || S <= 12)) {
+    if (mode != 0 && s.ldb >= 1024 && (mode == 3 || mode == 5 || S <= 16)) {
         hipLaunchKernelGGL(ov_bn_fwd_wide_kernel, dim3(d.L), dim3(256), 0, s.st, s.ws.slab, S, mode == 5 ? (int64_t)(2 * d.L + 1) : (int64_t)d.L * s.ldb,
                            c->P + c->lay.b0, c->P + c->lay.gamma, c->P + c->lay.beta, c->bn_rmean, c->bn_rvar, c->bn_nbt,
                            s.ws.xhat, s.ws.a, s.ws.bn_mean, s.ws.bn_invstd, stats, d.L, s.B, Bglobal, s.ldb, mode, c->drop, c->seed,
