@@ -2085,14 +2085,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // index / weight fetches and their ds_swizzle broadcasts leave the inner loop (a group's 8 lanes read one record: a broadcast).
 template <int NU>
 struct OvTermEnt { int32_t row; float w[NU]; };
-template <int NU, int WPE>
+// ACC: the weight-gradient dots of the workgroup's blocks are added up in LDS (one accumulator per link and neuron, touched by one
+// lane only, blocks in ascending order: a fixed summation order without atomics) and written once, as partial copy cb0: the
+// gene layer's links then have min(ncb, 8) partial copies instead of ncb (64 at 2048 columns) for the finish pass to add.
+// acc_off: byte offset of the accumulators behind the records (the largest tile's record area).
+template <int NU, int WPE, bool ACC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ov_bwd_gene_term_lds_kernel(
         const int32_t* __restrict__ csc_row, const float* __restrict__ vals, float* __restrict__ d, float* __restrict__ dblk, int C,
         int ldb, int ncb, int ntiles, const float* __restrict__ act, float* __restrict__ wpart, int64_t nnz,
-        const int4* __restrict__ tiles) {
+        const int4* __restrict__ tiles, int acc_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ov_tl_raw[];
     __shared__ int sh_off[33];
     OvTermEnt<NU>* ent = reinterpret_cast<OvTermEnt<NU>*>(ov_tl_raw);
+    float* wacc = reinterpret_cast<float*>(ov_tl_raw + acc_off);
     // workgroup -> (first column block, tile): as ov_cb_map, but a workgroup keeps its tile for every block of its XCD
     const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
     int cb0, cbstep, tile;
@@ -2117,6 +2122,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
         for (int j = 0; j < NU; ++j) t.w[j] = vals[kb + j * len + e];
         ent[off + e] = t;
+        if (ACC) {          // entry e belongs to lane e & 7 of this group from here to the end
+#pragma unroll
+            for (int j = 0; j < NU; ++j) wacc[(off + e) * NU + j] = 0.f;
+        }
     }
     __syncthreads();
     int maxlen = len;                    // wave maximum of len
@@ -2169,7 +2178,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             }
             if (b0 + s < len) {
 #pragma unroll
-                for (int j = 0; j < NU; ++j) part[kb + j * len + b0 + s] = mine[j];
+                for (int j = 0; j < NU; ++j) {
+                    if (ACC) wacc[(off + b0 + s) * NU + j] += mine[j];
+                    else part[kb + j * len + b0 + s] = mine[j];
+                }
             }
         }
         if (node < C) {
@@ -2178,6 +2190,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 *reinterpret_cast<f32x4*>(d + (int64_t)(node + j) * ldb + col0 + s4) = acc[j];
                 if (dblk) *reinterpret_cast<f32x4*>(dblk + ((int64_t)(cb * 8 + s) * C + node + j) * 4) = acc[j];
             }
+        }
+    }
+    if (ACC) {
+        float* part = wpart + (int64_t)cb0 * nnz;
+        for (int e = s; e < len; e += 8) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) part[kb + j * len + e] = wacc[(off + e) * NU + j];
         }
     }
 }
@@ -2324,6 +2343,7 @@ __global__ __launch_bounds__(256) void ov_wgrad_cb_kernel(const OvWgradArgs a) {
 // plain gradient; the same for the biases of the rows.
 struct OvFinishArgs {
     const float* part; const float* bpart; int ncb;
+    int ncb_gene;       // partial copies of the GENE layer's links (k >= nnz_term): ncb, or fewer when the backward gene kernel added blocks up itself
     int64_t nnz; int nrows, first_term_node, n_term_rows, C;
     float* vals; float* mvals; float* vvals; float* gvals;
     float* bias; float* mbias; float* vbias; float* gbias;
@@ -2350,14 +2370,15 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
         // the column blocks' partials in a fixed order; eight loads in flight (at 256 blocks this pass reads 0.5 GB)
         float g = 0.f;
         int cb = 0;
-        for (; cb + 8 <= a.ncb; cb += 8) {
+        const int ncopies = k >= a.nnz_term ? a.ncb_gene : a.ncb;
+        for (; cb + 8 <= ncopies; cb += 8) {
             float t[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) t[j] = a.part[(int64_t)(cb + j) * a.nnz + k];
 #pragma unroll
             for (int j = 0; j < 8; ++j) g += t[j];
         }
-        for (; cb < a.ncb; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
+        for (; cb < ncopies; ++cb) g += a.part[(int64_t)cb * a.nnz + k];
         update(k, g);
     }
     auto update_bias = [&](int node, float g) {
@@ -3490,6 +3511,21 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne, bool term_part_only = fal
     return ONTOVAE_OK;
 }
 
+// the backward gene kernel of this pass is the term-tile form with its lists in LDS (needs s.gw_part: the weight gradient rides there)
+static bool ov_bwd_gene_lds_form(const OvStep& s) {
+    const ontovae_ctx_t* c = s.c;
+    const int tp_mode = OV_DBG((c->flags >> 26) & 3);
+    const size_t tl_lds = (size_t)c->tpanel_max_entries * (1 + c->dims.nu) * 4;
+    if (c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES) return false;
+    if (s.tdrop.rate > 0.f || ov_fused_bt(c) == 0) return false;          // per-level path: ov_dec_backward returns before the gene kernels
+    if (!c->tpanel_tiles || c->dims.nu < 1 || c->dims.nu > 3 || tp_mode == 1 || tp_mode == 2) return false;
+    return c->tpanel_max_entries > 0 && tl_lds <= 48 * 1024 && ((s.ldb >= 512 && s.ldb < 4096) || tp_mode == 3);
+}
+// ... and adds the column blocks' weight-gradient dots up in LDS (three workgroups per CU must still fit: 160 KB)
+static bool ov_bwd_gene_acc(const OvStep& s) {
+    const size_t lds = (size_t)s.c->tpanel_max_entries * (1 + 2 * s.c->dims.nu) * 4;
+    return ov_bwd_gene_lds_form(s) && lds <= 52 * 1024;
+}
 #define OV_RIDE_PCT 75      // share of the gene rows whose weight gradient rides in the backward chain's launch (flat from 55 to 100)
 // wg: gene rows of the weight gradient to run in the same launch as the backward chain (fused path only), or NULL;
 // *wg_done tells the caller whether that happened
@@ -3530,15 +3566,19 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
         // below 512 columns the per-node kernel stays (4 x more workgroups for the few blocks there are: 20.6 us at 128 columns).
         const size_t tl_lds = (size_t)c->tpanel_max_entries * (1 + d.nu) * 4;
         const bool term_ok = c->tpanel_tiles && s.gw_part && d.nu >= 1 && d.nu <= 3 && tp_mode != 1;
-        if (term_ok && tp_mode != 2 && c->tpanel_max_entries > 0 && tl_lds <= 48 * 1024 && ((s.ldb >= 512 && s.ldb < 4096) || tp_mode == 3)) {
+        if (term_ok && ov_bwd_gene_lds_form(s)) {
             const int tt = (d.C / d.nu + 31) / 32;
             const int4* tl = reinterpret_cast<const int4*>(c->tpanel_tiles);
             const int grid = ncb <= 8 ? ov_cb_grid(ncb, tt) : 8 * tt;
-#define OV_BG_L(N, W) do { if ((rc = ov_set_lds(ov_bwd_gene_term_lds_kernel<N, W>, tl_lds))) return rc;                          \
-                           hipLaunchKernelGGL((ov_bwd_gene_term_lds_kernel<N, W>), dim3(grid), dim3(256), tl_lds, s.st, c->csc_row, vals, s.ws.d, blk, d.C, \
-                           s.ldb, ncb, tt, s.ws.act, s.gw_part, (int64_t)d.nnz, tl); } while (0)
+            const bool wacc = ov_bwd_gene_acc(s);
+            const size_t lds = tl_lds + (wacc ? (size_t)c->tpanel_max_entries * d.nu * 4 : 0);
+#define OV_BG_L2(N, W, A) do { if ((rc = ov_set_lds(ov_bwd_gene_term_lds_kernel<N, W, A>, lds))) return rc;                      \
+                           hipLaunchKernelGGL((ov_bwd_gene_term_lds_kernel<N, W, A>), dim3(grid), dim3(256), lds, s.st, c->csc_row, vals, s.ws.d, blk, d.C, \
+                           s.ldb, ncb, tt, s.ws.act, s.gw_part, (int64_t)d.nnz, tl, (int)tl_lds); } while (0)
+#define OV_BG_L(N, W) do { if (wacc) OV_BG_L2(N, W, true); else OV_BG_L2(N, W, false); } while (0)
             if (d.nu == 1) OV_BG_L(1, 4); else if (d.nu == 2) OV_BG_L(2, 4); else OV_BG_L(3, 3);
 #undef OV_BG_L
+#undef OV_BG_L2
             OV_LAUNCH_CHECK();
         } else if (term_ok && (s.ldb >= 4096 || tp_mode == 2)) {
             const int tt = (d.C / d.nu + 31) / 32;
@@ -3990,7 +4030,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         wt.tiles = (wt.nrows_part == n_term_rows && wt.first_term_node == 0) ? reinterpret_cast<const int4*>(c->term_tiles) : nullptr;
         wteams = ov_cb_grid(wt.ncb, wt.ntiles);
         fblocks = (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 2048);
-        fa = OvFinishArgs{wa.part, wa.bpart, wa.ncb, (int64_t)d.nnz, wrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,
+        fa = OvFinishArgs{wa.part, wa.bpart, wa.ncb, fused_gw && ov_bwd_gene_acc(s) ? std::min(wa.ncb, 8) : wa.ncb, (int64_t)d.nnz, wrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,
                           c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                           G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
                           c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam,
