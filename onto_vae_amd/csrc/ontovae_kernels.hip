@@ -3519,7 +3519,10 @@ static bool ov_bwd_gene_lds_form(const OvStep& s) {
     if (c->flags & ONTOVAE_FLAG_WIDE_GENE_TILES) return false;
     if (s.tdrop.rate > 0.f || ov_fused_bt(c) == 0) return false;          // per-level path: ov_dec_backward returns before the gene kernels
     if (!c->tpanel_tiles || c->dims.nu < 1 || c->dims.nu > 3 || tp_mode == 1 || tp_mode == 2) return false;
-    return c->tpanel_max_entries > 0 && tl_lds <= 48 * 1024 && ((s.ldb >= 512 && s.ldb < 4096) || tp_mode == 3);
+    // without room for the accumulators (ov_bwd_gene_acc) only below 4096 columns: beyond, one partial copy per block made this form slower
+    // than the block-major kernel (680 against 612 us at 4096 columns, 1386 / 1183 at 8192); with them it is 462 and 958 us
+    const bool acc = tl_lds / (1 + c->dims.nu) * (1 + 2 * c->dims.nu) <= 52 * 1024;
+    return c->tpanel_max_entries > 0 && tl_lds <= 48 * 1024 && ((s.ldb >= 512 && (s.ldb < 4096 || acc)) || tp_mode == 3);
 }
 // ... and adds the column blocks' weight-gradient dots up in LDS (three workgroups per CU must still fit: 160 KB)
 static bool ov_bwd_gene_acc(const OvStep& s) {
@@ -3560,8 +3563,9 @@ static int ov_dec_backward(OvStep& s, const OvFinishArgs* fin = nullptr, int fbl
         // a gene's D row is gathered once for the term's nu nodes
         const int tp_mode = OV_DBG((c->flags >> 26) & 3);       // measurement builds: 1 = per-node kernel even so
         // Which form (measured, GO-BP, us at 1024 / 2048 / 4096 / 8192 columns; per-node kernel 164 / 316 / 657 / 1263):
-        //   term tiles, lists in LDS, a workgroup walks all blocks of its XCD : 158 / 291 / 680 / 1386  (the tiles drift apart over
-        //                                                                      many blocks and several blocks' D rows share the L2)
+        //   term tiles, lists in LDS, a workgroup walks all blocks of its XCD : 158 / 291 / 680 / 1386  with one partial copy of the
+        //                                                                      weight gradient per block,
+        //                                                                      107 / 222 / 462 /  958  with the blocks added up in LDS
         //   term tiles, block-major as the per-node kernel                   :   - /   - / 612 / 1183
         // below 512 columns the per-node kernel stays (4 x more workgroups for the few blocks there are: 20.6 us at 128 columns).
         const size_t tl_lds = (size_t)c->tpanel_max_entries * (1 + d.nu) * 4;

@@ -6,8 +6,8 @@ shift
 for B in "$@"; do
 for V in base alt; do
   if [ $V = base ]; then unset ONTOVAE_HIP_LIB; else export ONTOVAE_HIP_LIB=$GRAFT_REPO_ROOT/scratch/libontovae_alt.so; fi
-  timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${V}_b$B -o t -- python3 profiling/one_step.py 20 $B train > $O/${V}_b$B.log 2>&1
+  timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${V}_b$B -o t -- python3 profiling/one_step.py 12 $B train > $O/${V}_b$B.log 2>&1
 done
-python3 profiling/stats_table.py 20:$O/base_b$B/t_kernel_stats.csv 20:$O/alt_b$B/t_kernel_stats.csv > $O/table_$B.txt
+python3 profiling/stats_table.py 12:$O/base_b$B/t_kernel_stats.csv 12:$O/alt_b$B/t_kernel_stats.csv > $O/table_$B.txt
 done
 echo done
