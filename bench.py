@@ -68,10 +68,11 @@ def phase_cost(name, d, B, nnz_t, dtype="f32"):
     nnz_g = nnz - nnz_t
     r = step_regime(B, C_)
     ncb = r["ncb"]
+    ncp = min(ncb, 8)          # partial copies of the gene layer's weight gradient: a workgroup of the backward gene kernel adds up the column blocks of its XCD
     f = 4
     nterm = C_ - L                                                       # term rows of the decoder (their biases too)
     gb_part = G * (B // 4 if r["lds"] else ncb)                          # gene bias partials: per column group of 4 (LDS kernel) or per block
-    gene_finish = ((nnz_g * ncb + gb_part) + 6 * (nnz_g + G)) * f        # partials in; w, m, v of links and biases in and out
+    gene_finish = ((nnz_g * ncp + gb_part) + 6 * (nnz_g + G)) * f        # partials in; w, m, v of links and biases in and out
     gene_finish_fl = 12.0 * (nnz_g + G)
     term_finish = ((nnz_t + nterm) * ncb + 6 * (nnz_t + nterm)) * f
     cost = {
@@ -84,7 +85,7 @@ def phase_cost(name, d, B, nnz_t, dtype="f32"):
         # gene layer + ELBO: links, panel in, x in, dL/drecon out, gene bias partials out
         "dec_fwd_gene": ((2 * nnz_g + C_ * B + 2 * G * B + gb_part) * f, 2.0 * nnz_g * B),
         # gene part of the backward + the gene layer's weight-gradient partials: links, D genes in, D panel out, partials out
-        "dec_bwd_gene": ((2 * nnz_g + (C_ + G) * B + nnz_g * ncb) * f, 4.0 * nnz_g * B),
+        "dec_bwd_gene": ((2 * nnz_g + (C_ + G) * B + nnz_g * ncp) * f, 4.0 * nnz_g * B),
         # term part of the backward: links, D panel in and out
         "dec_bwd": ((2 * nnz_t + 2 * C_ * B) * f, 2.0 * nnz_t * B),
         # d mu / d log_var; rider: weight-gradient partials of the term rows (panel and D rows in, partials out)

@@ -1,3 +1,6 @@
+# Same-box A/B of two builds of the library: traces `one_step.py 12 <rows> train` with the in-tree library ("base") and with
+# scratch/libontovae_alt.so ("alt", through ONTOVAE_HIP_LIB) and puts the two kernel tables side by side.
+#   bash profiling/ab_trace.sh <tag> <rows> [<rows> ...]   ->  gpurun_out/ab_<tag>/table_<rows>.txt
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
