@@ -2204,27 +2204,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // Backward data, one wave per (panel node of the level, batch chunk), CSC gather:
 //   D[p, :] = sum_q vals[csc_k[q]] * D[csc_row[q], :]
 // csc_split != NULL: the term part of the lists only, added to what D[p, :] holds (the gene part, from ov_bwd_gene_cb_kernel)
+// tw.part != NULL (training steps at large batches, no dropout): the wave has every D row of the node's term links in registers,
+// so it also forms their weight-gradient dots with ACT[node] over its chunk of columns (partial copy blockIdx.y of the term
+// layers' links: one per 64 VEC columns instead of one per 32 from riders that gathered the rows again) and the chunk's share of
+// the bias gradient of its own row.
+struct OvLvlWgrad { const float* act; float* part; float* bpart; int64_t nnz; int nrows, n_term_rows; };
 template <int VEC>
 __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restrict__ cscptr, const int32_t* __restrict__ csc_row,
                                                         const int32_t* __restrict__ csc_k, const float* __restrict__ vals,
                                                         float* __restrict__ d, int node_begin, int node_end, int ldb,
-                                                        const int32_t* __restrict__ csc_split, const OvTermDrop dr, int n_drop) {
+                                                        const int32_t* __restrict__ csc_split, const OvTermDrop dr, int n_drop,
+                                                        const OvLvlWgrad tw) {
     const int node = node_begin + blockIdx.x * 4 + ov_wave_id();
     if (node >= node_end) return;
     const int b0 = blockIdx.y * (64 * VEC) + ov_lane() * VEC;
-    float acc[VEC];
+    const bool wg = tw.part != nullptr;
+    float acc[VEC], an[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int j = 0; j < VEC; ++j) { acc[j] = 0.f; an[j] = 0.f; }
     const int q0 = cscptr[node], q1 = csc_split ? csc_split[node] : cscptr[node + 1];
     if (csc_split) {
-        if (q1 == q0) return;                      // no term children: the row is final
+        if (q1 == q0 && !(wg && node < tw.n_term_rows)) return;          // no term children: the row is final
         ov_ldv<VEC>(d + (int64_t)node * ldb + b0, acc);
     }
+    if (wg) ov_ldv<VEC>(tw.act + (int64_t)node * ldb + b0, an);
+    float* part = wg ? tw.part + (int64_t)blockIdx.y * tw.nnz : nullptr;
+    auto dot = [&](const float (&v)[VEC]) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) t += v[j] * an[j];
+        return t;
+    };
     int q = q0;
     for (; q + 4 <= q1; q += 4) {
         float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
         const int r0 = csc_row[q], r1 = csc_row[q + 1], r2 = csc_row[q + 2], r3 = csc_row[q + 3];
-        const float w0 = vals[csc_k[q]], w1 = vals[csc_k[q + 1]], w2 = vals[csc_k[q + 2]], w3 = vals[csc_k[q + 3]];
+        const int k0 = csc_k[q], k1 = csc_k[q + 1], k2 = csc_k[q + 2], k3 = csc_k[q + 3];
+        const float w0 = vals[k0], w1 = vals[k1], w2 = vals[k2], w3 = vals[k3];
         ov_ldv<VEC>(d + (int64_t)r0 * ldb + b0, v0);
         ov_ldv<VEC>(d + (int64_t)r1 * ldb + b0, v1);
         ov_ldv<VEC>(d + (int64_t)r2 * ldb + b0, v2);
@@ -2236,14 +2252,31 @@ __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restri
             acc[j] += w2 * v2[j];
             acc[j] += w3 * v3[j];
         }
+        if (wg) {
+            const float t0 = ov_wave_sum(dot(v0)), t1 = ov_wave_sum(dot(v1)), t2 = ov_wave_sum(dot(v2)), t3 = ov_wave_sum(dot(v3));
+            if (ov_lane() == 0) { part[k0] = t0; part[k1] = t1; part[k2] = t2; part[k3] = t3; }
+        }
     }
     for (; q < q1; ++q) {
         float v0[VEC];
         const int r0 = csc_row[q];
-        const float w0 = vals[csc_k[q]];
+        const int k0 = csc_k[q];
+        const float w0 = vals[k0];
         ov_ldv<VEC>(d + (int64_t)r0 * ldb + b0, v0);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] += w0 * v0[j];
+        if (wg) {
+            const float t0 = ov_wave_sum(dot(v0));
+            if (ov_lane() == 0) part[k0] = t0;
+        }
+    }
+    if (wg && node < tw.n_term_rows) {              // bias gradient of this row: its finished D over the chunk's columns
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) t += acc[j];
+        t = ov_wave_sum(t);
+        if (ov_lane() == 0) tw.bpart[(int64_t)blockIdx.y * tw.nrows + node] = t;
+        if (q1 == q0) return;                       // D[node] is unchanged
     }
     if (dr.rate > 0.f && node < n_drop) {        // term nodes only: the rows of the operator's input carry no dropout
 #pragma unroll
@@ -2344,6 +2377,7 @@ __global__ __launch_bounds__(256) void ov_wgrad_cb_kernel(const OvWgradArgs a) {
 struct OvFinishArgs {
     const float* part; const float* bpart; int ncb;
     int ncb_gene;       // partial copies of the GENE layer's links (k >= nnz_term): ncb, or fewer when the backward gene kernel added blocks up itself
+    int ncb_term;       // ... of the term layers' links and of the term rows' bias partials: ncb, or one per chunk of columns from the per-level backward kernels
     int64_t nnz; int nrows, first_term_node, n_term_rows, C;
     float* vals; float* mvals; float* vvals; float* gvals;
     float* bias; float* mbias; float* vbias; float* gbias;
@@ -2370,7 +2404,7 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
         // the column blocks' partials in a fixed order; eight loads in flight (at 256 blocks this pass reads 0.5 GB)
         float g = 0.f;
         int cb = 0;
-        const int ncopies = k >= a.nnz_term ? a.ncb_gene : a.ncb;
+        const int ncopies = k >= a.nnz_term ? a.ncb_gene : a.ncb_term;
         for (; cb + 8 <= ncopies; cb += 8) {
             float t[8];
 #pragma unroll
@@ -2418,11 +2452,14 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
     }
     const int rb = terms ? 0 : a.n_term_rows, re = (genes && !a.gb4) ? a.nrows : a.n_term_rows;
     auto node_of_row = [&](int64_t r) { return r < a.n_term_rows ? a.first_term_node + (int)r : a.C + ((int)r - a.n_term_rows); };
-    if (a.ncb >= 16) {
+    // copies of the rows this pass covers: one kind of row, or both kinds with the same count
+    const bool gene_rows = genes && !a.gb4;
+    const int nbr = (terms && !gene_rows) ? a.ncb_term : a.ncb;
+    if (nbr >= 16 && (!terms || !gene_rows || a.ncb_term == a.ncb)) {
         // many column blocks: 16 rows per wave, the blocks in 4 runs of eight loads in flight, run sums added in run order
         // (the term layers' 8640 rows alone were 118 us at 8192 batch rows as one thread per row, 256 loads one behind the other)
         const int ii = (int)(first & 15), seg = (int)((first >> 4) & 3);
-        const int per = (a.ncb + 3) / 4, c0 = seg * per, c1 = min(c0 + per, a.ncb);
+        const int per = (nbr + 3) / 4, c0 = seg * per, c1 = min(c0 + per, nbr);
         for (int64_t r0 = rb + (first >> 6) * 16; r0 < re; r0 += (stride >> 6) * 16) {        // wave-uniform trip count
             const int64_t r = r0 + ii;
             float g = 0.f;
@@ -2444,7 +2481,8 @@ __device__ __forceinline__ void ov_wgrad_finish_body(const OvFinishArgs& a, cons
     }
     for (int64_t r = rb + first; r < re; r += stride) {
         float g = 0.f;
-        for (int cb = 0; cb < a.ncb; ++cb) g += a.bpart[(int64_t)cb * a.nrows + r];
+        const int ncopies = r < a.n_term_rows ? a.ncb_term : a.ncb;
+        for (int cb = 0; cb < ncopies; ++cb) g += a.bpart[(int64_t)cb * a.nrows + r];
         update_bias(node_of_row(r), g);
     }
 }
@@ -3033,6 +3071,8 @@ struct OvStep {
     // training, column-block kernels: the gene layer's weight gradient is formed inside the gene-layer kernels themselves
     // (bias partials in the forward kernel, link partials in the backward kernel); NULL = not wanted
     float* gw_part; float* gw_bpart; int gw_rows, gw_row0;
+    // ... and the term layers' inside the per-level backward kernels (large batches; ov_lvl_wgrad_on), one partial copy per chunk of columns
+    float* tw_part; float* tw_bpart;
     bool gene_lds;           // the gene layer's forward of this pass is ov_gene_lds_kernel (entry points that compute the loss set it)
     OvTermDrop tdrop;        // dropout on the term layers' outputs (OntoEncoder training passes); rate 0 everywhere else
 };
@@ -3503,8 +3543,11 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne, bool term_part_only = fal
     dim3 grid((ne - nb + 3) / 4, s.nchunk);
     const float* vals = c->P + c->lay.dec_vals;
     OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
+    // the term layers' weight gradient rides here (ov_lvl_wgrad_on): only with the term part of the lists and without dropout
+    const bool tw_on = term_part_only && s.tw_part && s.tdrop.rate <= 0.f;
+    const OvLvlWgrad tw{s.ws.act, tw_on ? s.tw_part : nullptr, s.tw_bpart, (int64_t)c->dims.nnz, s.gw_rows, c->dims.C - c->dims.L};
 #define OV_DB(V) hipLaunchKernelGGL((ov_dec_bwd_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_row, c->csc_k, vals, s.ws.d, nb, ne, s.ldb, \
-                                    term_part_only ? c->csc_split : (const int32_t*)nullptr, s.tdrop, c->dims.C - c->dims.L)
+                                    term_part_only ? c->csc_split : (const int32_t*)nullptr, s.tdrop, c->dims.C - c->dims.L, tw)
     if (s.vec == 1) OV_DB(1); else if (s.vec == 2) OV_DB(2); else OV_DB(4);
 #undef OV_DB
     OV_LAUNCH_CHECK();
@@ -3663,6 +3706,7 @@ static int ov_make_step(const ontovae_ctx_t* ctx, const float* x, const int32_t*
     s->fm_ld = 0;
     s->want_xT = false;
     s->gw_part = nullptr; s->gw_bpart = nullptr; s->gw_rows = 0; s->gw_row0 = 0;
+    s->tw_part = nullptr; s->tw_bpart = nullptr;
     s->gene_lds = false;
     s->tdrop = OvTermDrop{0.f, 0, 0};
     return ONTOVAE_OK;
@@ -4034,7 +4078,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
         wt.tiles = (wt.nrows_part == n_term_rows && wt.first_term_node == 0) ? reinterpret_cast<const int4*>(c->term_tiles) : nullptr;
         wteams = ov_cb_grid(wt.ncb, wt.ntiles);
         fblocks = (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 2048);
-        fa = OvFinishArgs{wa.part, wa.bpart, wa.ncb, fused_gw && ov_bwd_gene_acc(s) ? std::min(wa.ncb, 8) : wa.ncb, (int64_t)d.nnz, wrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,
+        fa = OvFinishArgs{wa.part, wa.bpart, wa.ncb, fused_gw && ov_bwd_gene_acc(s) ? std::min(wa.ncb, 8) : wa.ncb, wa.ncb, (int64_t)d.nnz, wrows, 0, n_term_rows, d.C, c->P + lay.dec_vals,
                           c->M ? c->M + lay.dec_vals : nullptr, c->V ? c->V + lay.dec_vals : nullptr,
                           G_ ? G_ + lay.dec_vals : nullptr, c->P + lay.dec_bias, c->M ? c->M + lay.dec_bias : nullptr,
                           c->V ? c->V + lay.dec_bias : nullptr, G_ ? G_ + lay.dec_bias : nullptr, apply, adam,
@@ -4054,6 +4098,14 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
                                : (int)std::min<int64_t>(((int64_t)d.nnz + 255) / 256, 256);        // 256-thread ones, one per CU (350 us for the launch at 8192 rows; 367 with 512, 391 with 2048)
             fblocks = (int)std::min<int64_t>(((int64_t)d.nnz_term + d.C + 255) / 256, 2048);
         }
+    }
+    // from 4096 columns on the term part of the backward is one launch per level (ov_dec_backward: per_level), and each of those
+    // waves holds exactly the rows the term layers' weight gradient needs: formed there, one partial copy per chunk of 256
+    // columns, instead of by riders of the latent backward that gather every row again (one copy per 32 columns)
+    if (ride_lat && s.ldb >= OV_CHAIN_FWD_MAX_LDB && s.tdrop.rate <= 0.f && ov_fused_bt(c) != 0) {
+        s.tw_part = wa.part; s.tw_bpart = wa.bpart;
+        fa.ncb_term = s.nchunk;
+        wteams = 0;
     }
     if ((rc = ov_dec_backward(s, ride_fin ? &fa_gene : nullptr, gblocks))) return rc;
     // fork: the decoder's weight gradients need nothing from the encoder backward, and vice versa
