@@ -56,7 +56,7 @@ def step_regime(B, C_=9000):
     lds = 160 * 1024 - 2048
     bt = 4 if C_ * 16 <= lds else (2 if C_ * 8 <= lds else 1)          # ov_fused_bt: batch columns of the panel a workgroup holds
     fin = "dec_bwd" if ldb // bt <= 128 else ("latent_bwd" if ldb >= 512 else "da_gemm")
-    return {"ldb": ldb, "ncb": ldb // 32, "gene_finish_in": fin, "lds": ldb >= 512, "levels": ldb >= 2048}
+    return {"ldb": ldb, "ncb": ldb // 32, "gene_finish_in": fin, "lds": ldb >= 512, "levels": ldb >= 4096}
 
 
 def phase_cost(name, d, B, nnz_t, dtype="f32"):
@@ -74,7 +74,11 @@ def phase_cost(name, d, B, nnz_t, dtype="f32"):
     gb_part = G * (B // 4 if r["lds"] else ncb)                          # gene bias partials: per column group of 4 (LDS kernel) or per block
     gene_finish = ((nnz_g * ncp + gb_part) + 6 * (nnz_g + G)) * f        # partials in; w, m, v of links and biases in and out
     gene_finish_fl = 12.0 * (nnz_g + G)
-    term_finish = ((nnz_t + nterm) * ncb + 6 * (nnz_t + nterm)) * f
+    # the term layers' weight-gradient partials: one copy per 32 columns from riders of the latent backward, or (one launch per level,
+    # from 4096 columns) one per 256 columns from the backward level kernels themselves
+    lv = r["levels"]
+    nct = r["ldb"] // 256 if lv else ncb
+    term_finish = ((nnz_t + nterm) * nct + 6 * (nnz_t + nterm)) * f
     cost = {
         "enc_gemm": ((L * G + B * G + L * B) * f, 2.0 * L * G * B),                 # W0, x once, h out
         "bn_fwd": (3 * L * B * f, 10.0 * L * B),                                    # h in, xhat + a out
@@ -87,9 +91,10 @@ def phase_cost(name, d, B, nnz_t, dtype="f32"):
         # gene part of the backward + the gene layer's weight-gradient partials: links, D genes in, D panel out, partials out
         "dec_bwd_gene": ((2 * nnz_g + (C_ + G) * B + nnz_g * ncp) * f, 4.0 * nnz_g * B),
         # term part of the backward: links, D panel in and out
-        "dec_bwd": ((2 * nnz_t + 2 * C_ * B) * f, 2.0 * nnz_t * B),
+        "dec_bwd": ((2 * nnz_t + 2 * C_ * B + (C_ * B + (nnz_t + nterm) * nct if lv else 0)) * f, (4.0 if lv else 2.0) * nnz_t * B),
         # d mu / d log_var; rider: weight-gradient partials of the term rows (panel and D rows in, partials out)
-        "latent_bwd": ((6 * L * B + (C_ + nterm) * B + (nnz_t + nterm) * ncb + 2 * nnz_t) * f, 16.0 * L * B + 2.0 * nnz_t * B),
+        "latent_bwd": ((6 * L * B + (0 if lv else (C_ + nterm) * B + (nnz_t + nterm) * nct + 2 * nnz_t)) * f,
+                       16.0 * L * B + (0.0 if lv else 2.0 * nnz_t * B)),
         # da = Wh^T [dmu; dlv]; rider: finish pass of the term layers
         "da_gemm": ((2 * L * L + 3 * L * B) * f + term_finish, 4.0 * L * L * B + 12.0 * (nnz_t + nterm)),
         "dwh": ((6 * 2 * L * L + 3 * L * B + 4 * L * B) * f, 4.0 * L * L * B),      # dWh + AdamW, BatchNorm backward

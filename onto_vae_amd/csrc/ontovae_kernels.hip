@@ -2227,7 +2227,7 @@ __global__ __launch_bounds__(256) void ov_dec_bwd_kernel(const int32_t* __restri
         if (q1 == q0 && !(wg && node < tw.n_term_rows)) return;          // no term children: the row is final
         ov_ldv<VEC>(d + (int64_t)node * ldb + b0, acc);
     }
-    if (wg) ov_ldv<VEC>(tw.act + (int64_t)node * ldb + b0, an);
+    if (wg && q1 > q0) ov_ldv<VEC>(tw.act + (int64_t)node * ldb + b0, an);          // (a node without term children only has its bias partial to form)
     float* part = wg ? tw.part + (int64_t)blockIdx.y * tw.nnz : nullptr;
     auto dot = [&](const float (&v)[VEC]) {
         float t = 0.f;
