@@ -246,6 +246,10 @@ typedef struct ontovae_ctx {
  * relative per step, pathway activities cosine >= 0.999 per sample.  Needs ctx->bf16_ws, ctx->Gr (dW0 is staged there) and
  * G % 8 == 0.  The gathered-dh data-parallel form (ontovae_dw0_global) stays fp32. */
 #define ONTOVAE_FLAG_BF16_GEMM     32u
+#define ONTOVAE_FLAG_PER_BLOCK_WGRAD 64u /* one partial copy of the decoder's weight gradient per 32-column block at every batch size: the backward
+                                           gene kernel without its LDS accumulators, the term layers' weight gradient from riders of the latent backward
+                                           instead of the per-level backward kernels (the path of an ontology whose tiles do not fit the accumulators;
+                                           tests compare the two) */
 #define ONTOVAE_FLAG_NO_RIDERS     16u  /* weight gradient of the gene rows as its own launch instead of inside the backward chain's */
 #define ONTOVAE_FLAG_SIDE_STREAM    4u  /* run the decoder weight gradient and dWh on a library-owned second stream, forked from
                                            and joined into the caller's stream with events (off by default: on this pool the event

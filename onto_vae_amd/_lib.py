@@ -189,6 +189,7 @@ EXPORTED = ["ontovae_last_error", "ontovae_abi_version", "ontovae_plan_create", 
             "ontovae_profile_begin", "ontovae_profile_read", "ontovae_profile_end", "ontovae_profile_overhead"]
 
 FLAG_BF16_GEMM = 32
+FLAG_PER_BLOCK_WGRAD = 64    # decoder weight-gradient partials per column block everywhere (no LDS accumulators, no level-kernel weight gradient)
 FLAG_CB_GENE_FWD = 128       # training forward of the gene layer on 32-column blocks instead of the LDS-panel kernel (tests compare the two)
 
 PHASES = ["enc_gemm", "bn_fwd", "heads", "reparam", "dec_fwd_terms", "dec_fwd_gene", "dec_bwd", "loss", "dec_wgrad",

@@ -25,7 +25,7 @@
 
 #define OV_LAUNCH_CHECK() OV_HIP_CHECK(hipGetLastError())
 
-#define OV_KNOWN_FLAGS (ONTOVAE_FLAG_LEVEL_LAUNCHES | ONTOVAE_FLAG_ROW_GENE_LAYER | ONTOVAE_FLAG_SIDE_STREAM | ONTOVAE_FLAG_WIDE_GENE_TILES | ONTOVAE_FLAG_NO_RIDERS | ONTOVAE_FLAG_BF16_GEMM | ONTOVAE_FLAG_CB_GENE_FWD)
+#define OV_KNOWN_FLAGS (ONTOVAE_FLAG_LEVEL_LAUNCHES | ONTOVAE_FLAG_ROW_GENE_LAYER | ONTOVAE_FLAG_SIDE_STREAM | ONTOVAE_FLAG_WIDE_GENE_TILES | ONTOVAE_FLAG_NO_RIDERS | ONTOVAE_FLAG_BF16_GEMM | ONTOVAE_FLAG_CB_GENE_FWD | ONTOVAE_FLAG_PER_BLOCK_WGRAD)
 
 // batch columns per wave pass (64 lanes x VEC) and the padded row length, a multiple of it
 // -------------------------------------------------------------------------------------------------
@@ -3564,13 +3564,13 @@ static bool ov_bwd_gene_lds_form(const OvStep& s) {
     if (!c->tpanel_tiles || c->dims.nu < 1 || c->dims.nu > 3 || tp_mode == 1 || tp_mode == 2) return false;
     // without room for the accumulators (ov_bwd_gene_acc) only below 4096 columns: beyond, one partial copy per block made this form slower
     // than the block-major kernel (680 against 612 us at 4096 columns, 1386 / 1183 at 8192); with them it is 462 and 958 us
-    const bool acc = tl_lds / (1 + c->dims.nu) * (1 + 2 * c->dims.nu) <= 52 * 1024;
+    const bool acc = tl_lds / (1 + c->dims.nu) * (1 + 2 * c->dims.nu) <= 52 * 1024 && !(c->flags & ONTOVAE_FLAG_PER_BLOCK_WGRAD);
     return c->tpanel_max_entries > 0 && tl_lds <= 48 * 1024 && ((s.ldb >= 512 && (s.ldb < 4096 || acc)) || tp_mode == 3);
 }
 // ... and adds the column blocks' weight-gradient dots up in LDS (three workgroups per CU must still fit: 160 KB)
 static bool ov_bwd_gene_acc(const OvStep& s) {
     const size_t lds = (size_t)s.c->tpanel_max_entries * (1 + 2 * s.c->dims.nu) * 4;
-    return ov_bwd_gene_lds_form(s) && lds <= 52 * 1024;
+    return ov_bwd_gene_lds_form(s) && lds <= 52 * 1024 && !(s.c->flags & ONTOVAE_FLAG_PER_BLOCK_WGRAD);
 }
 #define OV_RIDE_PCT 75      // share of the gene rows whose weight gradient rides in the backward chain's launch (flat from 55 to 100)
 // wg: gene rows of the weight gradient to run in the same launch as the backward chain (fused path only), or NULL;
@@ -4102,7 +4102,7 @@ static int ov_train_tail_a(OvStep& s, const float* eps, uint64_t rng_off, float 
     // from 4096 columns on the term part of the backward is one launch per level (ov_dec_backward: per_level), and each of those
     // waves holds exactly the rows the term layers' weight gradient needs: formed there, one partial copy per chunk of 256
     // columns, instead of by riders of the latent backward that gather every row again (one copy per 32 columns)
-    if (ride_lat && s.ldb >= OV_CHAIN_FWD_MAX_LDB && s.tdrop.rate <= 0.f && ov_fused_bt(c) != 0) {
+    if (ride_lat && s.ldb >= OV_CHAIN_FWD_MAX_LDB && s.tdrop.rate <= 0.f && ov_fused_bt(c) != 0 && !(c->flags & ONTOVAE_FLAG_PER_BLOCK_WGRAD)) {
         s.tw_part = wa.part; s.tw_bpart = wa.bpart;
         fa.ncb_term = s.nchunk;
         wteams = 0;

@@ -394,7 +394,8 @@ def test_gradients_vs_oracle(B, flags):
     check_gradients(B, flags)
 
 
-@pytest.mark.parametrize("B,flags", [(1100, 0), (1100, 1), (1100, 16), (2100, 0), (2100, 1), (2100, 16), (4200, 0)])
+@pytest.mark.parametrize("B,flags", [(1100, 0), (1100, 1), (1100, 16), (1100, 64), (2100, 0), (2100, 1), (2100, 16), (2100, 64), (4200, 0),
+                                     (4200, 64)])
 def test_gradients_vs_oracle_ragged_large_batches(B, flags):
     """The kernels that take over from 1024 / 2048 columns, on shapes with every kind of tail (1000 genes: K not a multiple of the
     32-deep step of the two-stage encoder product; 1100 / 2100 rows: padded columns in the whole-workgroup BatchNorm passes, a
@@ -444,7 +445,9 @@ def check_gradients(B, flags, seed=None, tol=2e-5):
     e = model._engine
     # 1: per-level launches, 2: row-per-wave gene layer (the general-purpose variants), 4: side stream,
     # 8: wide gene-layer tiles instead of 32-column blocks, 16: no riders in the backward chain's launch,
-    # 128: the gene layer's training forward on 32-column blocks instead of the LDS-panel kernel (0 runs that one)
+    # 128: the gene layer's training forward on 32-column blocks instead of the LDS-panel kernel (0 runs that one),
+    # 64: one partial copy of the decoder's weight gradient per column block (0: the backward gene kernel adds its blocks up in LDS, and
+    # from 4096 columns the per-level backward kernels form the term layers' weight gradient)
     e.flags = flags
     e.invalidate()
     out = torch.zeros(3, device="cuda")
