@@ -3071,7 +3071,7 @@ struct OvStep {
     // training, column-block kernels: the gene layer's weight gradient is formed inside the gene-layer kernels themselves
     // (bias partials in the forward kernel, link partials in the backward kernel); NULL = not wanted
     float* gw_part; float* gw_bpart; int gw_rows, gw_row0;
-    // ... and the term layers' inside the per-level backward kernels (large batches; ov_lvl_wgrad_on), one partial copy per chunk of columns
+    // ... and the term layers' inside the per-level backward kernels (large batches; set by ov_train_tail_a), one partial copy per chunk of columns
     float* tw_part; float* tw_bpart;
     bool gene_lds;           // the gene layer's forward of this pass is ov_gene_lds_kernel (entry points that compute the loss set it)
     OvTermDrop tdrop;        // dropout on the term layers' outputs (OntoEncoder training passes); rate 0 everywhere else
@@ -3543,7 +3543,7 @@ static int ov_dec_bwd_level(OvStep& s, int nb, int ne, bool term_part_only = fal
     dim3 grid((ne - nb + 3) / 4, s.nchunk);
     const float* vals = c->P + c->lay.dec_vals;
     OvProfScope prof(ONTOVAE_PHASE_DEC_BWD, s.st);
-    // the term layers' weight gradient rides here (ov_lvl_wgrad_on): only with the term part of the lists and without dropout
+    // the term layers' weight gradient rides here (s.tw_part, set by the training step from 4096 columns on): only with the term part of the lists and without dropout
     const bool tw_on = term_part_only && s.tw_part && s.tdrop.rate <= 0.f;
     const OvLvlWgrad tw{s.ws.act, tw_on ? s.tw_part : nullptr, s.tw_bpart, (int64_t)c->dims.nnz, s.gw_rows, c->dims.C - c->dims.L};
 #define OV_DB(V) hipLaunchKernelGGL((ov_dec_bwd_kernel<V>), grid, dim3(256), 0, s.st, c->cscptr, c->csc_row, c->csc_k, vals, s.ws.d, nb, ne, s.ldb, \
